@@ -1,0 +1,335 @@
+// k-space data-fidelity stage of the PnP-ADMM iteration for gfx950 (MI355X).
+//
+// Replaces, per iteration (/root/reference/evaluation/env.py:87-93):
+//     z = fft(x + u);  z[mask] = ((mu*z + y0)/(1+mu))[mask];  z = ifft(z);  u = u + x - z
+// where fft/ifft are the centred orthonormal transforms of evaluation/utils/transformations.py:6-19
+// (ifftshift -> fftn/ifftn(norm='ortho') -> fftshift, i.e. 4 roll copies per iteration).
+//
+// Shift folding (H, W even): with S = fftshift and sgn[k1,k2] = (-1)^(k1+k2),
+//     ifft_c(where(m, (mu*fft_c(v) + y0)/(1+mu), fft_c(v)))
+//   = IFFT(where(S m, (mu*FFT(v) + sgn*S y0)/(1+mu), FFT(v)))          (plain, unshifted transforms)
+// so pnp_reset pre-shifts the mask and y0 once and the iteration moves no roll traffic at all.
+//
+// Three launches, each a Stockham autosort FFT (radix-4 passes + one radix-2 pass when log2 L is odd)
+// held entirely in LDS, HBM traffic coalesced in >= 128-B runs:
+//   rows-forward : v = x + u -> row FFT -> work                       (reads 12 B/px, writes 8)
+//   cols + prox  : column FFT -> masked closed-form solve -> inverse column FFT, in place in `work`
+//                  (16 adjacent columns per workgroup so every global access is a 128-B line)
+//   rows-inverse : row IFFT -> z;  u += x - z                         (reads 20 B/px, writes 16)
+// Twiddles come from a host-computed (double precision) table.
+#include "pnp_internal.h"
+
+namespace pnp {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// `lines` independent length-L transforms, line i at [i*lstr, i*lstr+L) of src; ping-pongs src <-> dst.
+// tw[m] = exp(-2 pi i m / L) in LDS.  Caller has synchronised the loads; returns the buffer holding the
+// result (synchronised).
+template <bool INV>
+__device__ float2* fft_lines(float2* src, float2* dst, const float2* tw, int L, int lines, int lstr) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    int Ns = 1;
+    const int per4 = L >> 2;
+    while (Ns * 4 <= L) {
+        const int total = lines * per4;
+        const int tstep = L / (4 * Ns);
+        for (int idx = tid; idx < total; idx += nth) {
+            const int line = idx / per4, j = idx - line * per4;
+            const int k = j & (Ns - 1);
+            const float2* sp = src + line * lstr + j;
+            float2 v0 = sp[0], v1 = sp[per4], v2 = sp[2 * per4], v3 = sp[3 * per4];
+            if (Ns > 1) {
+                float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+            }
+            const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3);
+            const float2 d = csub(v1, v3);
+            const float2 t3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+/- i) * d
+            float2* dp = dst + line * lstr + ((j - k) << 2) + k;
+            dp[0] = cadd(t0, t2);
+            dp[Ns] = cadd(t1, t3);
+            dp[2 * Ns] = csub(t0, t2);
+            dp[3 * Ns] = csub(t1, t3);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+        Ns <<= 2;
+    }
+    if (Ns < L) {   // one radix-2 pass (Ns == L/2)
+        const int per2 = L >> 1;
+        const int total = lines * per2;
+        for (int idx = tid; idx < total; idx += nth) {
+            const int line = idx / per2, j = idx - line * per2;
+            const int k = j & (Ns - 1);
+            const float2* sp = src + line * lstr + j;
+            float2 v0 = sp[0], v1 = sp[per2];
+            float2 w = tw[k * (L / (2 * Ns))];
+            if (INV) w.y = -w.y;
+            v1 = cmul(v1, w);
+            float2* dp = dst + line * lstr + ((j - k) << 1) + k;
+            dp[0] = cadd(v0, v1);
+            dp[Ns] = csub(v0, v1);
+        }
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in the row passes
+
+// MODE 0 generic (in -> out, index shifts), 1 ADMM forward (x + u -> work), 2 ADMM inverse (work -> z, u)
+template <int MODE>
+__global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2* out,
+                                                       const float* __restrict__ x, float2* __restrict__ u,
+                                                       const float2* __restrict__ twg, const float* __restrict__ tact,
+                                                       int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2* buf0 = smem;
+    float2* buf1 = smem + rpb * W;
+    float2* tw = smem + 2 * rpb * W;
+    const int blocks_per_img = H / rpb;
+    const int n = blockIdx.x / blocks_per_img;
+    const int y0 = (blockIdx.x % blocks_per_img) * rpb;
+    if (MODE != 0 && tact != nullptr && tact[n] > 0.5f) return;
+    const size_t base = ((size_t)n * H + y0) * W;
+    const int tot = rpb * W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) tw[i] = twg[i];
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const int r = e / W, c = e - r * W;
+        float2 v;
+        if (MODE == 1) {
+            const float2 uu = u[base + e];
+            v = make_float2(x[base + e] + uu.x, uu.y);
+        } else {
+            v = in[base + (size_t)r * W + (c ^ shift_in)];
+        }
+        buf0[e] = v;
+    }
+    __syncthreads();
+    const bool inv = (MODE == 2) || (MODE == 0 && inverse);
+    float2* res = inv ? fft_lines<true>(buf0, buf1, tw, W, rpb, W) : fft_lines<false>(buf0, buf1, tw, W, rpb, W);
+    const float sc = rsqrtf((float)W);
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const int r = e / W, c = e - r * W;
+        float2 v = res[e];
+        v.x *= sc; v.y *= sc;
+        if (MODE == 2) {
+            const size_t g = base + e;
+            const float2 uu = u[g];
+            out[g] = v;                                            // z
+            u[g] = make_float2(uu.x + x[g] - v.x, uu.y - v.y);     // u + x - z
+        } else {
+            out[base + (size_t)r * W + (c ^ shift_out)] = v;
+        }
+    }
+}
+
+// Column pass over CW adjacent columns of one slice.  MODE 0 generic in-place transform with row-index
+// shifts; MODE 1 forward -> prox -> inverse (ADMM).
+template <int MODE>
+__global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data, const float2* __restrict__ twg,
+                                                       const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
+                                                       int mask_n, const float* __restrict__ mu,
+                                                       const float* __restrict__ tact, int H, int W, int cw,
+                                                       int inverse, int shift_in, int shift_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int lstr = H + 1;
+    float2* buf0 = smem;
+    float2* buf1 = smem + cw * lstr;
+    float2* tw = smem + 2 * cw * lstr;
+    const int strips = W / cw;
+    const int n = blockIdx.x / strips;
+    const int x0 = (blockIdx.x % strips) * cw;
+    if (MODE == 1 && tact != nullptr && tact[n] > 0.5f) return;
+    float2* img = data + (size_t)n * H * W;
+    const int tot = cw * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) tw[i] = twg[i];
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const int r = e / cw, c = e - r * cw;
+        buf0[c * lstr + (r ^ shift_in)] = img[(size_t)r * W + x0 + c];
+    }
+    __syncthreads();
+    const float sc = rsqrtf((float)H);
+    if (MODE == 0) {
+        float2* res = inverse ? fft_lines<true>(buf0, buf1, tw, H, cw, lstr) : fft_lines<false>(buf0, buf1, tw, H, cw, lstr);
+        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+            const int r = e / cw, c = e - r * cw;
+            float2 v = res[c * lstr + (r ^ shift_out)];
+            v.x *= sc; v.y *= sc;
+            img[(size_t)r * W + x0 + c] = v;
+        }
+    } else {
+        float2* res = fft_lines<false>(buf0, buf1, tw, H, cw, lstr);
+        float2* oth = (res == buf0) ? buf1 : buf0;
+        const float m = mu[n];
+        const float inv1m = 1.f + m;
+        const float2* y0n = y0s + (size_t)n * H * W;
+        const uint8_t* mk = masks + (mask_n > 1 ? (size_t)n * H * W : 0);
+        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+            const int r = e / cw, c = e - r * cw;
+            float2 v = res[c * lstr + r];
+            v.x *= sc; v.y *= sc;                               // now the orthonormal FFT2 of x + u
+            const size_t g = (size_t)r * W + x0 + c;
+            if (mk[g]) {                                        // sampled k-space bin: closed-form solve
+                const float2 yy = y0n[g];
+                v.x = (m * v.x + yy.x) / inv1m;
+                v.y = (m * v.y + yy.y) / inv1m;
+            }
+            res[c * lstr + r] = v;
+        }
+        __syncthreads();
+        float2* r2 = fft_lines<true>(res, oth, tw, H, cw, lstr);
+        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+            const int r = e / cw, c = e - r * cw;
+            float2 v = r2[c * lstr + r];
+            v.x *= sc; v.y *= sc;
+            img[(size_t)r * W + x0 + c] = v;
+        }
+    }
+}
+
+// The column pass needs up to ~74 KiB of dynamic LDS (H = 1024); raise the per-kernel cap once.
+static hipError_t raise_lds_cap() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)fft_cols_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+    return hipSuccess;
+}
+
+static inline int rows_per_block(int H, int W) {
+    int r = ROW_ELEMS / W;
+    if (r < 1) r = 1;
+    if (r > H) r = H;
+    return r;
+}
+static inline int cols_per_block(int H, int W) {
+    int c = H <= 256 ? 16 : (H <= 512 ? 8 : 4);
+    if (c > W) c = W;
+    return c;
+}
+
+hipError_t launch_fft_rows_generic(const float2* in, float2* out, const float2* tw, int batch, int H, int W, int inverse,
+                                   int shift_in, int shift_out, hipStream_t s) {
+    const int rpb = rows_per_block(H, W);
+    const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
+    hipLaunchKernelGGL(fft_rows_kernel<0>, dim3(batch * (H / rpb)), dim3(256), lds, s, in, out, nullptr, nullptr, tw,
+                       nullptr, H, W, rpb, inverse, shift_in, shift_out);
+    return hipGetLastError();
+}
+hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, int H, int W, int inverse, int shift_in,
+                                   int shift_out, hipStream_t s) {
+    const int cw = cols_per_block(H, W);
+    const size_t lds = (size_t)(2 * cw * (H + 1) + H) * sizeof(float2);
+    if (hipError_t e = raise_lds_cap()) return e;
+    hipLaunchKernelGGL(fft_cols_kernel<0>, dim3(batch * (W / cw)), dim3(256), lds, s, data, tw, nullptr, nullptr, 1,
+                       nullptr, nullptr, H, W, cw, inverse, shift_in, shift_out);
+    return hipGetLastError();
+}
+hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* work, const float2* tw, const float* tact,
+                                    int N, int H, int W, hipStream_t s) {
+    const int rpb = rows_per_block(H, W);
+    const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
+    hipLaunchKernelGGL(fft_rows_kernel<1>, dim3(N * (H / rpb)), dim3(256), lds, s, nullptr, work, x,
+                       const_cast<float2*>(u), tw, tact, H, W, rpb, 0, 0, 0);
+    return hipGetLastError();
+}
+hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0s, const uint8_t* masks, int mask_n,
+                                const float* mu, const float* tact, int N, int H, int W, hipStream_t s) {
+    const int cw = cols_per_block(H, W);
+    const size_t lds = (size_t)(2 * cw * (H + 1) + H) * sizeof(float2);
+    if (hipError_t e = raise_lds_cap()) return e;
+    hipLaunchKernelGGL(fft_cols_kernel<1>, dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu,
+                       tact, H, W, cw, 0, 0, 0);
+    return hipGetLastError();
+}
+hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
+                                    const float* tact, int N, int H, int W, hipStream_t s) {
+    const int rpb = rows_per_block(H, W);
+    const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
+    hipLaunchKernelGGL(fft_rows_kernel<2>, dim3(N * (H / rpb)), dim3(256), lds, s, work, z, x, u, tw, tact, H, W, rpb,
+                       1, 0, 0);
+    return hipGetLastError();
+}
+
+// ---- reset: x = Re(x0), z = x0, u = 0; fold the fftshifts into the episode constants -------------
+__global__ void reset_kernel(const float2* __restrict__ x0, const float2* __restrict__ y0,
+                             const uint8_t* __restrict__ mask, int mask_n, float* __restrict__ x,
+                             float2* __restrict__ z, float2* __restrict__ u, float2* __restrict__ y0s,
+                             uint8_t* __restrict__ masks, int N, int H, int W) {
+    const size_t hw = (size_t)H * W, total = (size_t)N * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / hw, p = i - n * hw;
+        const int k1 = (int)(p / W), k2 = (int)(p - (size_t)k1 * W);
+        const float2 v = x0[i];
+        x[i] = v.x;
+        z[i] = v;
+        u[i] = make_float2(0.f, 0.f);
+        const size_t ps = (size_t)(k1 ^ (H >> 1)) * W + (k2 ^ (W >> 1));      // S: index + N/2 mod N (N power of two)
+        const float sg = ((k1 + k2) & 1) ? -1.f : 1.f;
+        const float2 yy = y0[n * hw + ps];
+        y0s[i] = make_float2(sg * yy.x, sg * yy.y);
+        if (mask_n > 1 || n == 0) masks[(mask_n > 1 ? n * hw : 0) + p] = mask[(mask_n > 1 ? n * hw : 0) + ps] ? 1 : 0;
+    }
+}
+
+hipError_t launch_reset(const float2* x0, const float2* y0, const uint8_t* mask, int mask_n, float* x, float2* z,
+                        float2* u, float2* y0s, uint8_t* masks, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, x0, y0, mask, mask_n, x, z, u, y0s, masks, N, H, W);
+    return hipGetLastError();
+}
+
+__global__ void finish_kernel(const float* __restrict__ tact, float* __restrict__ tstate, uint8_t* __restrict__ done,
+                              int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool d = tact != nullptr && tact[n] > 0.5f;
+    if (done != nullptr) done[n] = d ? 1 : 0;
+    if (tstate != nullptr && !d) tstate[n] += 1.0f / 30.0f;     // env.py:98
+}
+hipError_t launch_finish(const float* tact, float* tstate, uint8_t* done, int N, hipStream_t s) {
+    hipLaunchKernelGGL(finish_kernel, dim3((N + 63) / 64), dim3(64), 0, s, tact, tstate, done, N);
+    return hipGetLastError();
+}
+
+// ---- PSNR (env.py:120-125): one workgroup per slice, f64 accumulation of the squared error --------
+__global__ __launch_bounds__(1024) void psnr_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                    float* __restrict__ out, int HW) {
+    __shared__ double part[16];
+    const int n = blockIdx.x;
+    const float* xp = x + (size_t)n * HW;
+    const float* gp = gt + (size_t)n * HW;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float d = fminf(fmaxf(xp[i], 0.f), 1.f) - gp[i];
+        acc += (double)d * (double)d;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+        const double mse = t / (double)HW;
+        out[n] = (float)(10.0 * log10(1.0 / mse));
+    }
+}
+hipError_t launch_psnr(const float* x, const float* gt, float* out, int N, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(psnr_kernel, dim3(N), dim3(1024), 0, s, x, gt, out, HW);
+    return hipGetLastError();
+}
+
+}  // namespace pnp

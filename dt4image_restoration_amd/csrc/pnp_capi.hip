@@ -1,0 +1,390 @@
+// C ABI of libpnpadmm.so (declared in include/pnpadmm.h): engine object, weight ingest, launch
+// sequencing of one PnP-ADMM iteration, kernel-level event timing.
+#include "../../include/pnpadmm.h"
+#include "pnp_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pnp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PNP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kNParams = 11773857;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls, layer;
+};
+
+struct LevelBufs {
+    float* p;  // ping
+    float* q;  // pong
+    float* s;  // skip / stage output kept for the up path
+    int c, h, w;
+};
+
+}  // namespace
+
+struct pnp_engine {
+    pnp_config cfg;
+    bool weights_loaded = false;
+    bool reset_done = false;
+    // denoiser
+    float* d_wpack[N_LAYERS] = {};   // packed conv3x3 weights (layers 1..26), raw for 0 and 27
+    float* d_bias[N_LAYERS] = {};
+    LevelBufs lv[5] = {};
+    // data-fidelity stage
+    FftPlan plan = {};
+    float2* d_work = nullptr;   // [N,H,W] complex scratch
+    float2* d_y0s = nullptr;    // [N,H,W] sgn * S y0
+    uint8_t* d_masks = nullptr; // [mask_n,H,W] S mask
+    int mask_n = 1;
+    size_t ws_bytes = 0;
+    // profiling
+    std::vector<EventPair> events;
+    size_t ev_used = 0;
+    double cls_ms[PNP_PROFILE_CLASSES] = {};
+    int64_t cls_n[PNP_PROFILE_CLASSES] = {};
+    double layer_ms[N_LAYERS] = {};
+    int64_t layer_n[N_LAYERS] = {};
+};
+
+namespace {
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+struct Prof {
+    pnp_engine* e;
+    hipStream_t s;
+    EventPair* ep = nullptr;
+    Prof(pnp_engine* e_, hipStream_t s_, int cls, int layer) : e(e_), s(s_) {
+        if (!(e->cfg.flags & PNP_FLAG_PROFILE)) return;
+        if (e->ev_used == e->events.size()) {
+            EventPair p{};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            e->events.push_back(p);
+        }
+        ep = &e->events[e->ev_used++];
+        ep->cls = cls;
+        ep->layer = layer;
+        (void)hipEventRecord(ep->a, s);
+    }
+    ~Prof() {
+        if (ep) (void)hipEventRecord(ep->b, s);
+    }
+};
+
+int make_twiddles(int L, float2** out) {
+    std::vector<float2> t(L);
+    for (int m = 0; m < L; ++m) {
+        const double a = -2.0 * M_PI * (double)m / (double)L;
+        t[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    HIP_TRY(hipMalloc((void**)out, sizeof(float2) * L));
+    HIP_TRY(hipMemcpy(*out, t.data(), sizeof(float2) * L, hipMemcpyHostToDevice));
+    return PNP_OK;
+}
+
+// The 27 MFMA convs + first/last layer of one denoiser forward.  Image channel = ximg, or Re(z-u).
+int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u, const float* sigma,
+             const float* tact, float* out, hipStream_t s) {
+    const int N = e->cfg.n, H = e->cfg.h, W = e->cfg.w;
+    {
+        Prof p(e, s, 1, 0);
+        HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
+    }
+    auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl) -> int {
+        const LayerSpec& L = kLayers[li];
+        ConvArgs a{};
+        a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.tact = tact;
+        a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
+        if (L.src == SRC_UPCAT) {
+            const int hs = a.H / 2, ws = a.W / 2;
+            a.rh = a.H > 1 ? (float)(hs - 1) / (float)(a.H - 1) : 0.f;
+            a.rw = a.W > 1 ? (float)(ws - 1) / (float)(a.W - 1) : 0.f;
+        }
+        Prof p(e, s, 0, li);
+        HIP_TRY(launch_conv3x3(a, L.src, s));
+        return PNP_OK;
+    };
+    int rc;
+    // inc
+    if ((rc = conv(1, e->lv[0].p, nullptr, e->lv[0].q, 0))) return rc;
+    if ((rc = conv(2, e->lv[0].q, nullptr, e->lv[0].s, 0))) return rc;
+    // down1..4: conv-0 pools the previous level's stage output while staging
+    for (int k = 1; k <= 4; ++k) {
+        const int b = 3 * k;
+        if ((rc = conv(b, e->lv[k - 1].s, nullptr, e->lv[k].p, k))) return rc;
+        if ((rc = conv(b + 1, e->lv[k].p, nullptr, e->lv[k].q, k))) return rc;
+        if ((rc = conv(b + 2, e->lv[k].q, nullptr, e->lv[k].s, k))) return rc;
+    }
+    // up1..4: conv-0 reads cat([skip, bilinear_up(low)]) while staging
+    const float* low = e->lv[4].s;
+    for (int k = 3; k >= 0; --k) {
+        const int b = 15 + 3 * (3 - k);
+        if ((rc = conv(b, e->lv[k].s, low, e->lv[k].p, k))) return rc;
+        if ((rc = conv(b + 1, e->lv[k].p, nullptr, e->lv[k].q, k))) return rc;
+        if ((rc = conv(b + 2, e->lv[k].q, nullptr, e->lv[k].p, k))) return rc;
+        low = e->lv[k].p;
+    }
+    {
+        Prof p(e, s, 2, 27);
+        HIP_TRY(launch_conv_last(e->lv[0].p, ximg, z, u, tact, e->d_wpack[27], e->d_bias[27], out, N, H, W, s));
+    }
+    return PNP_OK;
+}
+
+int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float* x, float2* z, float2* u,
+                  hipStream_t s) {
+    const int N = e->cfg.n, H = e->cfg.h, W = e->cfg.w;
+    {
+        Prof p(e, s, 3, -1);
+        HIP_TRY(launch_fft_rows_fwd_admm(x, u, e->d_work, e->plan.tw_w, tact, N, H, W, s));
+    }
+    {
+        Prof p(e, s, 4, -1);
+        HIP_TRY(launch_fft_cols_prox(e->d_work, e->plan.tw_h, e->d_y0s, e->d_masks, e->mask_n, mu, tact, N, H, W, s));
+    }
+    {
+        Prof p(e, s, 3, -1);
+        HIP_TRY(launch_fft_rows_inv_admm(e->d_work, x, z, u, e->plan.tw_w, tact, N, H, W, s));
+    }
+    return PNP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pnp_last_error(void) { return g_err.c_str(); }
+const char* pnp_version(void) { return "pnpadmm 0.1 (gfx950, f32 MFMA)"; }
+
+int pnp_create(const pnp_config* cfg, pnp_handle* out) {
+    if (!cfg || !out) return fail(PNP_ERR_INVALID, "pnp_create: null argument");
+    if (cfg->n < 1 || cfg->h < 16 || cfg->w < 16 || cfg->h % 16 || cfg->w % 16)
+        return fail(PNP_ERR_INVALID, "pnp_create: need n >= 1 and h, w multiples of 16 (got n=%d h=%d w=%d)", cfg->n,
+                    cfg->h, cfg->w);
+    if (cfg->h > 1024 || cfg->w > 1024) return fail(PNP_ERR_INVALID, "pnp_create: h, w <= 1024");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(PNP_ERR_INVALID, "pnp_create: device %d of %d", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    pnp_engine* e = new pnp_engine();
+    e->cfg = *cfg;
+    const size_t N = cfg->n, H = cfg->h, W = cfg->w;
+    static const int chan[5] = {32, 64, 128, 256, 512};
+    for (int k = 0; k < 5; ++k) {
+        LevelBufs& L = e->lv[k];
+        L.c = chan[k]; L.h = (int)(H >> k); L.w = (int)(W >> k);
+        const size_t bytes = N * L.h * L.w * L.c * sizeof(float);
+        float** bufs[3] = {&L.p, &L.q, &L.s};
+        for (auto b : bufs) {
+            hipError_t er = hipMalloc((void**)b, bytes);
+            if (er != hipSuccess) { pnp_destroy(e); return fail(PNP_ERR_NOMEM, "activation planes: %s", hipGetErrorString(er)); }
+            e->ws_bytes += bytes;
+        }
+    }
+    const size_t cbytes = N * H * W * sizeof(float2);
+    if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||
+        hipMalloc((void**)&e->d_masks, N * H * W) != hipSuccess) {
+        pnp_destroy(e);
+        return fail(PNP_ERR_NOMEM, "k-space scratch");
+    }
+    e->ws_bytes += 2 * cbytes + N * H * W;
+    e->plan.h = cfg->h; e->plan.w = cfg->w;
+    int rc;
+    if ((rc = make_twiddles(cfg->h, &e->plan.tw_h)) || (rc = make_twiddles(cfg->w, &e->plan.tw_w))) { pnp_destroy(e); return rc; }
+    *out = e;
+    return PNP_OK;
+}
+
+int pnp_destroy(pnp_handle e) {
+    if (!e) return PNP_OK;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
+    for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); }
+    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks);
+    (void)hipFree(e->plan.tw_h); (void)hipFree(e->plan.tw_w);
+    for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    delete e;
+    return PNP_OK;
+}
+
+size_t pnp_workspace_bytes(pnp_handle e) { return e ? e->ws_bytes : 0; }
+
+int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
+    if (!e || !blob) return fail(PNP_ERR_INVALID, "pnp_load_unet_weights: null argument");
+    if (n_floats != kNParams)
+        return fail(PNP_ERR_INVALID, "pnp_load_unet_weights: expected %zu floats (56 tensors of UNet(2,1)), got %zu",
+                    kNParams, n_floats);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    size_t off = 0;
+    std::vector<float> tmp;
+    for (int li = 0; li < N_LAYERS; ++li) {
+        const LayerSpec& L = kLayers[li];
+        const size_t nw = (size_t)L.cout * L.cin * L.ksize * L.ksize;
+        const float* w = blob + off;
+        const float* b = blob + off + nw;
+        off += nw + L.cout;
+        (void)hipFree(e->d_wpack[li]); (void)hipFree(e->d_bias[li]);
+        e->d_wpack[li] = e->d_bias[li] = nullptr;
+        size_t pf;
+        const float* src;
+        if (li == 0 || li == N_LAYERS - 1) {   // first (2->32, OIHW as is) and last (1x1) layers
+            pf = nw; src = w;
+        } else {
+            pf = conv3x3_pack_floats(L.cin, L.cout);
+            tmp.resize(pf);
+            pack_conv3x3_weights(w, L.cin, L.cout, tmp.data());
+            src = tmp.data();
+        }
+        HIP_TRY(hipMalloc((void**)&e->d_wpack[li], pf * sizeof(float)));
+        HIP_TRY(hipMemcpy(e->d_wpack[li], src, pf * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&e->d_bias[li], L.cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(e->d_bias[li], b, L.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->weights_loaded = true;
+    return PNP_OK;
+}
+
+int pnp_reset(pnp_handle e, const float* x0, const float* y0, const uint8_t* mask, int mask_n, float* x, float* z,
+              float* u, void* stream) {
+    if (!e || !x0 || !y0 || !mask || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_reset: null argument");
+    if (mask_n != 1 && mask_n != e->cfg.n) return fail(PNP_ERR_INVALID, "pnp_reset: mask_n must be 1 or n=%d", e->cfg.n);
+    if (!is_pow2(e->cfg.h) || !is_pow2(e->cfg.w))
+        return fail(PNP_ERR_INVALID, "pnp_reset: the k-space stage needs power-of-two h, w (got %dx%d)", e->cfg.h, e->cfg.w);
+    e->mask_n = mask_n;
+    HIP_TRY(launch_reset((const float2*)x0, (const float2*)y0, mask, mask_n, x, (float2*)z, (float2*)u, e->d_y0s,
+                         e->d_masks, e->cfg.n, e->cfg.h, e->cfg.w, (hipStream_t)stream));
+    e->reset_done = true;
+    return PNP_OK;
+}
+
+int pnp_step(pnp_handle e, const float* mu, const float* sigma_d, const float* t_action, float* x, float* z, float* u,
+             float* t_state, uint8_t* done, void* stream) {
+    if (!e || !mu || !sigma_d || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_step: null argument");
+    if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_step: denoiser weights not loaded (pnp_load_unet_weights)");
+    if (!e->reset_done) return fail(PNP_ERR_STATE, "pnp_step: pnp_reset has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = run_unet(e, nullptr, (const float2*)z, (const float2*)u, sigma_d, t_action, x, s))) return rc;
+    if ((rc = run_prox_dual(e, mu, t_action, x, (float2*)z, (float2*)u, s))) return rc;
+    if (t_state || done) {
+        Prof p(e, s, 5, -1);
+        HIP_TRY(launch_finish(t_action, t_state, done, e->cfg.n, s));
+    }
+    return PNP_OK;
+}
+
+int pnp_denoise(pnp_handle e, const float* x_in, const float* sigma, float* out, void* stream) {
+    if (!e || !x_in || !sigma || !out) return fail(PNP_ERR_INVALID, "pnp_denoise: null argument");
+    if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_denoise: denoiser weights not loaded");
+    return run_unet(e, x_in, nullptr, nullptr, sigma, nullptr, out, (hipStream_t)stream);
+}
+
+int pnp_fft2c(pnp_handle e, const float* in, float* out, int batch, int hh, int ww, int inverse, void* stream) {
+    if (!e || !in || !out) return fail(PNP_ERR_INVALID, "pnp_fft2c: null argument");
+    if (hh != e->cfg.h || ww != e->cfg.w || batch < 1 || batch > e->cfg.n)
+        return fail(PNP_ERR_INVALID, "pnp_fft2c: shape [%d,%d,%d] does not fit the engine [%d,%d,%d]", batch, hh, ww,
+                    e->cfg.n, e->cfg.h, e->cfg.w);
+    if (!is_pow2(hh) || !is_pow2(ww)) return fail(PNP_ERR_INVALID, "pnp_fft2c: power-of-two sizes only");
+    hipStream_t s = (hipStream_t)stream;
+    // fft_c = S . FFT . S : fold both shifts into the load/store indices of the two passes
+    {
+        Prof p(e, s, 3, -1);
+        HIP_TRY(launch_fft_rows_generic((const float2*)in, (float2*)out, e->plan.tw_w, batch, hh, ww, inverse, ww / 2,
+                                        ww / 2, s));
+    }
+    {
+        Prof p(e, s, 4, -1);
+        HIP_TRY(launch_fft_cols_generic((float2*)out, e->plan.tw_h, batch, hh, ww, inverse, hh / 2, hh / 2, s));
+    }
+    return PNP_OK;
+}
+
+int pnp_prox_dual(pnp_handle e, const float* mu, const float* t_action, const float* x, float* z, float* u,
+                  void* stream) {
+    if (!e || !mu || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_prox_dual: null argument");
+    if (!e->reset_done) return fail(PNP_ERR_STATE, "pnp_prox_dual: pnp_reset has not been called");
+    return run_prox_dual(e, mu, t_action, x, (float2*)z, (float2*)u, (hipStream_t)stream);
+}
+
+int pnp_psnr(pnp_handle e, const float* x, const float* gt, float* out, void* stream) {
+    if (!e || !x || !gt || !out) return fail(PNP_ERR_INVALID, "pnp_psnr: null argument");
+    Prof p(e, (hipStream_t)stream, 5, -1);
+    HIP_TRY(launch_psnr(x, gt, out, e->cfg.n, e->cfg.h * e->cfg.w, (hipStream_t)stream));
+    return PNP_OK;
+}
+
+int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, int* ww, void* stream) {
+    if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
+    // stage outputs: inc, down1..4 live in lv[k].s; up1..4 in lv[3..0].p
+    const int lvl = which <= 4 ? which : 8 - which;
+    const LevelBufs& L = e->lv[lvl];
+    const float* src = which <= 4 ? L.s : L.p;
+    if (c) *c = L.c;
+    if (hh) *hh = L.h;
+    if (ww) *ww = L.w;
+    if (dst) HIP_TRY(launch_nhwc_to_nchw(src, dst, e->cfg.n, L.c, L.h, L.w, (hipStream_t)stream));
+    return PNP_OK;
+}
+
+int pnp_profile_reset(pnp_handle e) {
+    if (!e) return fail(PNP_ERR_INVALID, "null handle");
+    e->ev_used = 0;
+    memset(e->cls_ms, 0, sizeof e->cls_ms); memset(e->cls_n, 0, sizeof e->cls_n);
+    memset(e->layer_ms, 0, sizeof e->layer_ms); memset(e->layer_n, 0, sizeof e->layer_n);
+    return PNP_OK;
+}
+
+int pnp_profile_collect(pnp_handle e, double* total_ms, int64_t* launches) {
+    if (!e) return fail(PNP_ERR_INVALID, "null handle");
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->events[i].a, e->events[i].b));
+        const EventPair& p = e->events[i];
+        e->cls_ms[p.cls] += ms; e->cls_n[p.cls] += 1;
+        if (p.layer >= 0) { e->layer_ms[p.layer] += ms; e->layer_n[p.layer] += 1; }
+    }
+    e->ev_used = 0;
+    for (int i = 0; i < PNP_PROFILE_CLASSES; ++i) {
+        if (total_ms) total_ms[i] = e->cls_ms[i];
+        if (launches) launches[i] = e->cls_n[i];
+    }
+    return PNP_OK;
+}
+
+int pnp_profile_layers(pnp_handle e, double* layer_ms, int64_t* layer_launches) {
+    if (!e) return fail(PNP_ERR_INVALID, "null handle");
+    for (int i = 0; i < N_LAYERS; ++i) {
+        if (layer_ms) layer_ms[i] = e->layer_ms[i];
+        if (layer_launches) layer_launches[i] = e->layer_n[i];
+    }
+    return PNP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Internal declarations shared by the HIP translation units of libpnpadmm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace pnp {
+
+// ---- denoiser conv layer description (mirrors dt4image_restoration_amd/unet_spec.py) ----------
+enum SrcMode : int { SRC_PLAIN = 0, SRC_SIGMA = 1, SRC_POOL = 2, SRC_UPCAT = 3 };
+
+struct LayerSpec {
+    int cin, cout, ksize, level, src, cskip;
+};
+static constexpr int N_LAYERS = 28;
+extern const LayerSpec kLayers[N_LAYERS];
+
+// Arguments of one conv3x3 MFMA launch.  Activations are NHWC float32.
+struct ConvArgs {
+    const float* src0;   // PLAIN: [N,H,W,Cin]; POOL: [N,2H,2W,Cin]; UPCAT: skip [N,H,W,Cskip]
+    const float* src1;   // UPCAT: low-res [N,H/2,W/2,Cin-Cskip]; else unused
+    const float* wpack;  // packed weights, see pack_conv3x3_weights()
+    const float* bias;   // [Cout]
+    float* dst;          // [N,H,W,Cout]
+    const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
+    int N, H, W;         // OUTPUT spatial size
+    int Cin, Cskip, Cout;
+    int tilesX, tilesY;
+    float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
+};
+
+// Launch the conv3x3 (+bias +LeakyReLU 0.2) implicit-GEMM kernel matching `a` (picks the tile shape
+// from W and Cout).  Returns hipSuccess or the launch error.
+hipError_t launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s);
+
+// Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream.
+// dst must hold conv3x3_pack_floats(cin, cout) floats.
+size_t conv3x3_pack_floats(int cin, int cout);
+void pack_conv3x3_weights(const float* oihw, int cin, int cout, float* dst);
+
+// First layer (2 -> 32, K = 18: too thin for MFMA, direct VALU) and last layer (1x1 32 -> 1 fused
+// with the residual add and clamp).  `ximg` (f32 [N,H,W]) or, when null, Re(z-u) of complex64 z,u
+// is the image channel.
+hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
+                             const float* tact, const float* w, const float* bias, float* dst,
+                             int N, int H, int W, hipStream_t s);
+hipError_t launch_conv_last(const float* act, const float* ximg, const float2* z, const float2* u,
+                            const float* tact, const float* w, const float* bias, float* out,
+                            int N, int H, int W, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
+
+// ---- FFT / data-fidelity stage -----------------------------------------------------------------
+struct FftPlan {
+    int h, w;
+    float2* tw_h;   // device: exp(-2 pi i m / h), m < h
+    float2* tw_w;
+};
+
+// generic centred-or-plain passes (pnp_fft2c)
+hipError_t launch_fft_rows_generic(const float2* in, float2* out, const float2* tw, int batch, int H, int W,
+                                   int inverse, int shift_in, int shift_out, hipStream_t s);
+hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, int H, int W, int inverse,
+                                   int shift_in, int shift_out, hipStream_t s);
+// ADMM passes
+hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* work, const float2* tw,
+                                    const float* tact, int N, int H, int W, hipStream_t s);
+hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0s, const uint8_t* masks,
+                                int mask_n, const float* mu, const float* tact, int N, int H, int W, hipStream_t s);
+hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
+                                    const float* tact, int N, int H, int W, hipStream_t s);
+
+hipError_t launch_reset(const float2* x0, const float2* y0, const uint8_t* mask, int mask_n, float* x, float2* z,
+                        float2* u, float2* y0s, uint8_t* masks, int N, int H, int W, hipStream_t s);
+hipError_t launch_finish(const float* tact, float* tstate, uint8_t* done, int N, hipStream_t s);
+hipError_t launch_psnr(const float* x, const float* gt, float* out, int N, int HW, hipStream_t s);
+
+}  // namespace pnp

@@ -1,0 +1,137 @@
+/*
+ * pnpadmm.h - C ABI of libpnpadmm.so: the MI355X (gfx950) PnP-ADMM CS-MRI hot path.
+ *
+ * This is the drop-in boundary for ONE path of joesharratt1229/DT4Image_Restoration:
+ * the per-iteration loop of `PnPEnv.step` (evaluation/env.py:74-100) with its plug-in
+ * operators `UNetDenoiser2D.forward` (evaluation/noise.py:155-164) and the centred FFT pair
+ * (evaluation/utils/transformations.py:6-19).  The reference is pure Python, so "what its FFI
+ * would bind" is a flat function per reference method; each entry point below names the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer marked DEVICE is HIP device memory owned by the caller (e.g. a torch-ROCm
+ *     tensor's data_ptr()); HOST pointers are ordinary memory.  No torch types cross this ABI.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no entry point synchronises the device except pnp_create / pnp_load_unet_weights /
+ *     pnp_destroy (setup-time).
+ *   - real data is float32; complex data is complex64 = interleaved (re, im) float32, passed as
+ *     float*; images are [N,1,H,W] contiguous exactly like the reference's tensors.
+ *   - returns PNP_OK (0) or a negative pnp_status; pnp_last_error() gives the message of the last
+ *     failure on the calling thread.  A handle is not thread-safe; use one per GPU/process.
+ *   - H and W must be powers of two >= 16 for the ADMM step / FFT (the reference is hard-wired to
+ *     128, env.py:64) and multiples of 16 for the denoiser alone (noise.py:49-53 pad is then a no-op).
+ */
+#ifndef PNPADMM_H
+#define PNPADMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnp_engine* pnp_handle;
+
+typedef enum {
+    PNP_OK = 0,
+    PNP_ERR_INVALID = -1,      /* bad argument (NULL, shape, size not supported) */
+    PNP_ERR_HIP = -2,          /* a HIP runtime call failed; message has hipGetErrorString */
+    PNP_ERR_STATE = -3,        /* call order: weights not loaded / reset not done */
+    PNP_ERR_NOMEM = -4
+} pnp_status;
+
+typedef struct {
+    int32_t n;        /* slices resident on this GPU (batch); reference: 1 */
+    int32_t h, w;     /* slice size; reference: 128 x 128 */
+    int32_t device;   /* HIP device ordinal */
+    int32_t flags;    /* PNP_FLAG_* */
+} pnp_config;
+
+#define PNP_FLAG_PROFILE 1   /* record a HIP event pair around every kernel launch (pnp_profile_*) */
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Replaces: PnPEnv(max_episode_step, denoiser, device_type) construction (evaluation/env.py:31-33)
+ * minus the ARNIQA fetch (:34-40, out of scope).  Allocates the engine's private workspace
+ * (activation planes, FFT scratch, pre-shifted k-space constants). */
+int pnp_create(const pnp_config* cfg, pnp_handle* out);
+int pnp_destroy(pnp_handle h);
+const char* pnp_last_error(void);
+const char* pnp_version(void);
+
+/* Replaces: UNetDenoiser2D.__init__ -> net.load_state_dict (evaluation/noise.py:146-148).
+ * `blob` (HOST) = the 56 state_dict tensors concatenated in state_dict order
+ * (inc.conv.conv-0.conv2d.weight, .bias, ... outc.conv.weight, outc.conv.bias), weights OIHW
+ * float32 exactly as nn.Conv2d stores them; n_floats must be 11,773,857. */
+int pnp_load_unet_weights(pnp_handle h, const float* blob, size_t n_floats);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* Replaces: PnPEnv.reset (evaluation/env.py:57-71).
+ *   x0, y0 : DEVICE complex64 [N,1,H,W]  (view_as_complex of the .mat arrays)
+ *   mask   : DEVICE uint8 [H,W] (mask_n == 1, shared by all slices - the reference's case) or
+ *            [N,H,W] (mask_n == N)
+ * Writes   x (DEVICE float32 [N,1,H,W]) = Re(x0);  z = x0;  u = 0   (complex64 [N,1,H,W]),
+ * and stores the k-space constants of the episode inside the engine (fftshift-folded mask and
+ * y0), so `y0`/`mask` need not outlive the call. */
+int pnp_reset(pnp_handle h, const float* x0, const float* y0, const uint8_t* mask, int mask_n,
+              float* x, float* z, float* u, void* stream);
+
+/* Replaces: PnPEnv.step (evaluation/env.py:74-100), batched over the N resident slices.
+ *   mu, sigma_d : DEVICE float32 [N]  per-slice penalty and denoiser noise level (action_dict)
+ *   t_action    : DEVICE float32 [N] or NULL; slice n with t_action[n] > 0.5 is `done`: its
+ *                 x/z/u/t_state are left untouched (env.py:79-81)
+ *   x           : DEVICE float32 [N,1,H,W]  out: denoiser output (states['x'])
+ *   z, u        : DEVICE complex64 [N,1,H,W] in/out (states['z'], states['u'])
+ *   t_state     : DEVICE float32 [N] or NULL; += 1/30 for slices that stepped (env.py:98)
+ *   done        : DEVICE uint8 [N] or NULL; out: 1 where the slice was done */
+int pnp_step(pnp_handle h, const float* mu, const float* sigma_d, const float* t_action,
+             float* x, float* z, float* u, float* t_state, uint8_t* done, void* stream);
+
+/* ---- stage entry points (the reference's plug-in operators; also used by tests/profiling) ---- */
+
+/* Replaces: denoiser(x, sigma) = UNetDenoiser2D.forward (evaluation/noise.py:155-164):
+ * out = clamp(x + UNet(cat[x, sigma plane])[:, :1], 0, 1).  x_in/out DEVICE float32 [N,1,H,W]
+ * (may alias), sigma DEVICE float32 [N]. */
+int pnp_denoise(pnp_handle h, const float* x_in, const float* sigma, float* out, void* stream);
+
+/* Replaces: fft(img) / ifft(img) (evaluation/utils/transformations.py:6-12 / :14-19): centred
+ * (ifftshift -> fftn/ifftn norm='ortho' -> fftshift) 2-D transform over the last two dims.
+ * in/out DEVICE complex64 [batch,H,W] (may alias); batch*H*W must fit the engine's n*h*w. */
+int pnp_fft2c(pnp_handle h, const float* in, float* out, int batch, int hh, int ww, int inverse, void* stream);
+
+/* Replaces: the data-fidelity half of PnPEnv.step (evaluation/env.py:87-93) on its own:
+ * z <- ifft_c(where(mask, (mu*fft_c(x+u) + y0)/(1+mu), fft_c(x+u)));  u <- u + x - z.
+ * Uses the k-space constants stored by pnp_reset. */
+int pnp_prox_dual(pnp_handle h, const float* mu, const float* t_action, const float* x, float* z, float* u,
+                  void* stream);
+
+/* Replaces: PnPEnv.compute_reward -> torch_psnr (evaluation/env.py:112-125): per-slice
+ * 10*log10(1/mean((clamp(x,0,1)-gt)^2)).  x, gt DEVICE float32 [N,1,H,W]; out DEVICE float32 [N]. */
+int pnp_psnr(pnp_handle h, const float* x, const float* gt, float* out, void* stream);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+
+/* Copy one internal activation of the LAST denoiser forward to `dst` (DEVICE float32, NCHW
+ * [N,C,h,w]) for per-stage parity tests.  which: 0..8 = stage outputs inc, down1..4, up1..4
+ * (the tensors x1..x5, y1..y4 of evaluation/noise.py:120-128).  Returns C,h,w via out params. */
+int pnp_unet_read_stage(pnp_handle h, int which, float* dst, int* c, int* hh, int* ww, void* stream);
+
+/* Kernel-level timing (PNP_FLAG_PROFILE).  After the stream has been synchronised by the caller,
+ * pnp_profile_collect() folds the recorded event pairs into per-kernel-class totals.
+ * classes: 0 conv3x3_mfma, 1 conv_first (2->32, VALU), 2 conv_last (1x1 + residual + clamp),
+ *          3 fft_rows, 4 fft_cols_prox, 5 other.  Arrays of length PNP_PROFILE_CLASSES. */
+#define PNP_PROFILE_CLASSES 6
+int pnp_profile_reset(pnp_handle h);
+int pnp_profile_collect(pnp_handle h, double* total_ms, int64_t* launches);
+/* per-conv-layer totals (28 entries, execution order) from the same events */
+int pnp_profile_layers(pnp_handle h, double* layer_ms, int64_t* layer_launches);
+
+/* Engine workspace size in bytes (device memory owned by the handle). */
+size_t pnp_workspace_bytes(pnp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNPADMM_H */
