@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PnP-ADMM iterations/s on 256x256 CS-MRI, 64 slices per GPU (BASELINE.json
+configs[1]); one rank per GPU, slices sharded with no data-path collective (weak scaling).
+
+    python bench.py --gpus 1 --steps 30 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one `pnp_step` over the 64 slices resident on a GPU: U-Net denoiser forward, centred
+2-D FFT data-fidelity solve, dual update (the body of the reference's PnPEnv.step, env.py:74-100).
+Inputs are synthetic and already resident in HBM when the timed region starts.  Rank 0 prints ONE
+JSON line; see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are obtained.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dt4image_restoration_amd import synthetic, unet_spec, weights  # noqa: E402
+from dt4image_restoration_amd.engine import PnPEngine  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def mfma_conv_flops(n, h, w):
+    """Algorithmic FLOPs of the 26 conv3x3 layers that run on the MFMA kernel (all but the 2->32 first
+    layer and the 1x1 last layer), per step."""
+    return n * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level)
+                   for l in unet_spec.UNET_LAYERS[1:27])
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask and cgroup quota, not the machine's core count
+    (a 1-GPU box exposes 256 logical CPUs but grants a 16-core share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cap = int(os.environ.get("PNP_CPU_THREADS", "16"))
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sd_np, h, w, batch, slices, iters, mu_tab, sig_tab):
+    """Time the CPU oracle (oracle/pnp_oracle.py, torch CPU fp32) on `slices` slices x `iters`
+    iterations of the same workload; scaled linearly to batch-iterations/s."""
+    from oracle import pnp_oracle as O
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    data = synthetic.make_problem(slices, h, w, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    sd = O.torch_weights(sd_np)
+    with torch.no_grad():
+        O.run_episode(sd, data, mu_tab[:slices], sig_tab[:slices], 1, record_psnr=False)      # warm-up
+        t0 = time.perf_counter()
+        st, hist = O.run_episode(sd, data, mu_tab[:slices], sig_tab[:slices], iters)
+        dt = time.perf_counter() - t0
+    slice_iters_per_s = slices * iters / dt
+    return {"value": slice_iters_per_s / batch, "unit": "batch-iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{slices} slices x {iters} iterations of the {h}x{w} workload in {dt:.1f} s "
+                      f"({slice_iters_per_s:.2f} slice-iterations/s), scaled linearly to batch {batch}",
+            "slice_iters_per_s": slice_iters_per_s}, data, hist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-slices", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, h, w = args.batch, args.size, args.size
+    total_iters = args.steps + args.warmup
+    sd_np = weights.generate_unet_weights(0, "unit_gain")
+    # this rank's shard of the job: slices [rank*n, rank*n + n)
+    data = synthetic.make_problem(n, h, w, accel=4.0, sigma_n=10.0 / 255.0, seed=1234, first_slice=rank * n)
+    mu_tab, sig_tab = synthetic.param_table(n, total_iters, seed=77 + rank)
+
+    eng = PnPEngine(n, h, w, device=local_rank, profile=True)
+    eng.load_weights(sd_np)
+    x0 = torch.view_as_complex(torch.from_numpy(data["x0"])).to(dev)
+    y0 = torch.view_as_complex(torch.from_numpy(data["y0"])).to(dev)
+    mask = torch.from_numpy(data["mask"]).to(dev)
+    gt = torch.from_numpy(data["gt"]).to(dev)
+    mu_d = torch.from_numpy(mu_tab).to(dev).t().contiguous()       # [iters, n]
+    sg_d = torch.from_numpy(sig_tab).to(dev).t().contiguous()
+    x, z, u = eng.reset(x0, y0, mask)
+    psnr0 = eng.psnr(x, gt)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for t in range(args.warmup):
+        eng.step(x, z, u, mu_d[t], sg_d[t])
+    torch.cuda.synchronize()
+    eng.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total_iters):
+        eng.step(x, z, u, mu_d[t], sg_d[t])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_collect()
+    psnr1 = eng.psnr(x, gt)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    psnr_gain = (psnr1 - psnr0).mean().reshape(1).double()
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        # the path's only collective: gather the per-slice PSNR of every shard
+        allp = [torch.empty_like(psnr1) for _ in range(world)]
+        dist.all_gather(allp, psnr1)
+        psnr_all = torch.cat(allp)
+    else:
+        psnr_all = psnr1
+    elapsed = float(el.item())
+
+    if rank == 0:
+        steps = args.steps
+        value = world * steps / elapsed                           # batch-iterations/s over the whole job
+        conv_ms = prof["conv3x3_mfma"]["ms"]
+        conv_launches = prof["conv3x3_mfma"]["launches"]
+        flops_step = mfma_conv_flops(n, h, w)
+        achieved = flops_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+        out = {
+            "metric": "pnp_admm_iterations_per_sec", "value": round(value, 4), "unit": "batch-iterations/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {h}x{w} CS-MRI slices, batch {n} per GPU, U-Net denoiser + FFT prox, "
+                                   f"seeded per-slice (mu, sigma) table, 4x radial mask", "slices_per_gpu": n,
+                       "global_slices": n * world, "h": h, "w": w, "sharding": f"slices over {world} rank(s), no data-path collective"},
+            "slice_iterations_per_sec": round(value * n, 2),
+            "psnr_mean_db": round(float(psnr_all.mean()), 4),
+            "roofline": {
+                "kernel": "conv3x3_mfma_kernel (26 launches/step: all denoiser conv3x3 layers with Cin>=32)",
+                "bound": "mfma", "achieved": round(achieved, 3) if achieved else None, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                "traffic": None,
+                "flops_per_step": flops_step, "kernel_ms_per_step": round(conv_ms / steps, 4),
+                "launches_per_step": conv_launches / steps,
+                "other_kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()
+                                              if k not in ("layers", "conv3x3_mfma")},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            mu_c, sg_c = synthetic.param_table(n, total_iters, seed=77)
+            cb, cdata, chist = cpu_baseline(sd_np, h, w, n, args.cpu_slices, args.cpu_iters, mu_c, sg_c)
+            # PSNR delta vs the oracle on the same slices / same parameter prefix (fresh small engine)
+            e2 = PnPEngine(args.cpu_slices, h, w, device=local_rank)
+            e2.load_weights(sd_np)
+            cx0 = torch.view_as_complex(torch.from_numpy(cdata["x0"])).to(dev)
+            cy0 = torch.view_as_complex(torch.from_numpy(cdata["y0"])).to(dev)
+            x2, z2, u2 = e2.reset(cx0, cy0, torch.from_numpy(cdata["mask"]).to(dev))
+            gt2 = torch.from_numpy(cdata["gt"]).to(dev)
+            for t in range(args.cpu_iters):
+                e2.step(x2, z2, u2, torch.from_numpy(mu_c[:args.cpu_slices, t].copy()).to(dev),
+                        torch.from_numpy(sg_c[:args.cpu_slices, t].copy()).to(dev))
+            dpsnr = (e2.psnr(x2, gt2).cpu() - chist[:, -1]).abs().max()
+            cb.pop("slice_iters_per_s")
+            out["cpu_baseline"] = cb
+            out["psnr_delta_vs_oracle_db"] = float(dpsnr)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

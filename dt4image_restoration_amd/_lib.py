@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpnpadmm.so")
 
 PNP_FLAG_PROFILE = 1
+PNP_FLAG_NO_DENOISER = 2
 PROFILE_CLASSES = 6
 PROFILE_CLASS_NAMES = ("conv3x3_mfma", "conv_first", "conv_last", "fft_rows", "fft_cols_prox", "other")
 N_LAYERS = 28

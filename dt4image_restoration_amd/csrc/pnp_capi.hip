@@ -112,6 +112,8 @@ int make_twiddles(int L, float2** out) {
 int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u, const float* sigma,
              const float* tact, float* out, hipStream_t s) {
     const int N = e->cfg.n, H = e->cfg.h, W = e->cfg.w;
+    if (e->cfg.flags & PNP_FLAG_NO_DENOISER)
+        return fail(PNP_ERR_STATE, "this handle was created with PNP_FLAG_NO_DENOISER");
     {
         Prof p(e, s, 1, 0);
         HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
@@ -200,6 +202,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
     for (int k = 0; k < 5; ++k) {
         LevelBufs& L = e->lv[k];
         L.c = chan[k]; L.h = (int)(H >> k); L.w = (int)(W >> k);
+        if (cfg->flags & PNP_FLAG_NO_DENOISER) continue;   // k-space-only handle: no activation planes
         const size_t bytes = N * L.h * L.w * L.c * sizeof(float);
         float** bufs[3] = {&L.p, &L.q, &L.s};
         for (auto b : bufs) {

@@ -48,7 +48,8 @@ typedef struct {
     int32_t flags;    /* PNP_FLAG_* */
 } pnp_config;
 
-#define PNP_FLAG_PROFILE 1   /* record a HIP event pair around every kernel launch (pnp_profile_*) */
+#define PNP_FLAG_PROFILE 1       /* record a HIP event pair around every kernel launch (pnp_profile_*) */
+#define PNP_FLAG_NO_DENOISER 2   /* k-space-only handle (pnp_fft2c / pnp_psnr): no activation planes */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 

@@ -1,0 +1,209 @@
+"""The PnPEnv shim end to end on the GPU: trajectories against the golden vectors produced by the
+reference itself, early stop, batch semantics, in-place state + snapshot, determinism, and
+size-independent properties at the full BASELINE configs[1] size."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from dt4image_restoration_amd import synthetic, weights
+
+pytestmark = pytest.mark.gpu
+
+PSNR_TOL_DB = 0.01     # north_star: restored images within +-0.01 dB PSNR of the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def denoiser():
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    return UNetDenoiser2D.seeded(0, "unit_gain")
+
+
+def _env(denoiser):
+    from dt4image_restoration_amd.env import PnPEnv
+    return PnPEnv(max_episode_step=30, denoiser=denoiser, device_type="cuda")
+
+
+def _mat(data):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in data.items()}
+
+
+def test_config1_trajectory_matches_reference(denoiser, golden_dir):
+    """BASELINE configs[0]: 128x128, 4x radial mask, mu=0.1, sigma_d=15/255, 10 iterations - compared with
+    what the reference's own PnPEnv.step produced (g3_config1.npz)."""
+    g = np.load(os.path.join(golden_dir, "g3_config1.npz"))
+    env = _env(denoiser)
+    data = synthetic.make_problem(1, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    st = env.reset(_mat(data), "cuda")
+    ps = [float(env.compute_reward(st["x"].real.squeeze(0), st["gt"]))]
+    act = OrderedDict(T=torch.tensor(0.0), mu=torch.tensor(0.1), sigma_d=torch.tensor([15.0 / 255.0]))
+    for _ in range(10):
+        st, done = env.step(st, act)
+        assert done is False
+        ps.append(float(env.compute_reward(st["x"].reshape(1, 128, 128), st["gt"])))
+    assert np.abs(np.array(ps) - g["psnr_f32"]).max() < PSNR_TOL_DB
+    # FLOAT TOLERANCE: 10 iterations of f32 U-Net + FFTs; the reference's own f32-vs-f64 drift here is 7e-7
+    np.testing.assert_allclose(st["x"].cpu().numpy(), g["x_f32"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(torch.view_as_real(st["z"].cpu()).numpy(), g["z_f32"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(torch.view_as_real(st["u"].cpu()).numpy(), g["u_f32"], rtol=0, atol=2e-5)
+    assert abs(float(st["T"][0]) - float(g["T_f32"])) < 1e-5
+    # and closer to the f64 truth than the tolerance as well
+    assert np.abs(st["x"].cpu().numpy() - g["x_f64"]).max() < 2e-5
+
+
+def test_256_batch4_30_iterations_match_independent_reference_runs(denoiser, golden_dir):
+    """4 slices of 256x256 stepped as ONE batch with per-slice (mu, sigma) tables == 4 independent
+    single-slice runs of the reference (g4_256.npz), every iteration within the PSNR tolerance."""
+    g = np.load(os.path.join(golden_dir, "g4_256.npz"))
+    env = _env(denoiser)
+    data = synthetic.make_problem(4, 256, 256, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    st = env.reset(_mat(data), "cuda")
+    mu, sg = torch.from_numpy(g["mu_tab"]).cuda(), torch.from_numpy(g["sig_tab"]).cuda()
+    ps = np.zeros((4, 30))
+    for t in range(30):
+        st, done = env.step(st, {"T": torch.zeros(4), "mu": mu[:, t], "sigma_d": sg[:, t]})
+        assert not bool(done.any())
+        ps[:, t] = env.compute_reward(st["x"], st["gt"])[:, 0].numpy()
+    assert np.abs(ps - g["psnr"]).max() < PSNR_TOL_DB
+    np.testing.assert_allclose(st["x"].cpu().numpy()[:, 0], g["x_final"], rtol=0, atol=1e-4)
+
+
+def test_early_stop_matches_reference(denoiser, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_earlystop.npz"))
+    env = _env(denoiser)
+    st = env.reset(_mat(synthetic.make_problem(1, 128, 128, accel=4.0, seed=4321)), "cuda")
+    for t, Tact in enumerate((0.1, 0.3, 0.7, 0.2)):
+        st, done = env.step(st, {"T": torch.tensor(Tact), "mu": torch.tensor(0.2), "sigma_d": torch.tensor([20 / 255.0])})
+        assert done == bool(g[f"done_{t}"])
+        np.testing.assert_allclose(st["x"].cpu().numpy(), g[f"x_{t}"], rtol=0, atol=1e-5)
+        assert abs(float(st["T"][0]) - float(g[f"T_{t}"])) < 1e-5
+
+
+def test_per_slice_stop_leaves_done_slices_bit_identical(denoiser):
+    env = _env(denoiser)
+    st = env.reset(_mat(synthetic.make_problem(3, 64, 64, seed=5)), "cuda")
+    act = {"T": torch.zeros(3), "mu": torch.tensor([0.1, 0.2, 0.3]), "sigma_d": torch.tensor([0.05, 0.1, 0.15])}
+    st, _ = env.step(st, act)
+    before = env.snapshot(st)
+    act["T"] = torch.tensor([0.0, 0.9, 0.0])
+    st, done = env.step(st, act)
+    assert done.tolist() == [False, True, False]
+    for k in ("x", "z", "u"):
+        assert torch.equal(st[k][1], before[k][1])
+        assert not torch.equal(st[k][0], before[k][0])
+    assert float(st["T"][1]) == float(before["T"][1]) and float(st["T"][0]) > float(before["T"][0])
+
+
+def test_batch_equals_single_slice_runs_bitwise_and_deterministic(denoiser):
+    """Slices are independent units: slice i of a batch-3 run == the same slice run alone, bit for bit;
+    and the same call twice gives identical bits."""
+    data = synthetic.make_problem(3, 64, 64, seed=11)
+    mu = torch.tensor([0.1, 0.35, 0.6]); sg = torch.tensor([0.04, 0.1, 0.2])
+
+    def run(sel):
+        env = _env(denoiser)
+        d = {k: (v[sel] if k != "mask" else v) for k, v in data.items()}
+        st = env.reset(_mat(d), "cuda")
+        for _ in range(3):
+            st, _ = env.step(st, {"T": torch.zeros(len(sel)), "mu": mu[sel], "sigma_d": sg[sel]})
+        return {k: st[k].clone() for k in ("x", "z", "u")}
+
+    full = run([0, 1, 2])
+    again = run([0, 1, 2])
+    for k in full:
+        assert torch.equal(full[k], again[k])
+    for i in range(3):
+        one = run([i])
+        for k in full:
+            assert torch.equal(full[k][i], one[k][0]), (k, i)
+
+
+def test_snapshot_restore_and_inplace_state(denoiser):
+    env = _env(denoiser)
+    st = env.reset(_mat(synthetic.make_problem(2, 64, 64, seed=3)), "cuda")
+    act = {"T": torch.zeros(2), "mu": torch.tensor([0.2, 0.2]), "sigma_d": torch.tensor([0.1, 0.1])}
+    xptr = st["x"].data_ptr()
+    snap = env.snapshot(st)
+    st, _ = env.step(st, act)
+    assert st["x"].data_ptr() == xptr                       # updated in place (documented deviation)
+    a = {k: st[k].clone() for k in ("x", "z", "u")}
+    env.restore(st, snap)
+    st, _ = env.step(st, act)
+    for k in a:
+        assert torch.equal(a[k], st[k])
+
+
+def test_shim_error_behaviour(denoiser):
+    from dt4image_restoration_amd.env import PnPEnv
+    from dt4image_restoration_amd._lib import PnPError
+    env = _env(denoiser)
+    with pytest.raises(RuntimeError):
+        env.run_no_ref_reward({"x": torch.zeros(1, 1, 16, 16)})
+    with pytest.raises(RuntimeError):                         # sigma must have N elements (noise.py:159)
+        denoiser(torch.zeros(2, 1, 32, 32, device="cuda"), torch.zeros(3, device="cuda"))
+    with pytest.raises(PnPError):                             # non power-of-two k-space stage
+        env.reset(_mat(synthetic.make_problem(1, 48, 64, seed=1)), "cuda")
+    env2 = PnPEnv(30, denoiser, "cuda", no_ref_scorer=lambda x: float(x.mean()))
+    assert isinstance(env2.run_no_ref_reward({"x": torch.ones(1, 1, 16, 16)}), float)
+
+
+def test_fft_shims_match_golden(golden_dir):
+    from dt4image_restoration_amd.transformations import fft, ifft
+    g = np.load(os.path.join(golden_dir, "g1_fft.npz"))
+    for tag in ("16", "128", "16x32"):
+        c = torch.view_as_complex(torch.from_numpy(g[f"in_{tag}"].copy())).cuda()
+        np.testing.assert_allclose(torch.view_as_real(fft(c).cpu()).numpy(), g[f"fft_{tag}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(torch.view_as_real(ifft(c).cpu()).numpy(), g[f"ifft_{tag}"], rtol=0, atol=3e-6)
+
+
+# ---- full-size properties (BASELINE configs[1]: 256x256, batch 64) ------------------------------------
+def test_full_size_batch64_properties(denoiser):
+    from dt4image_restoration_amd.engine import PnPEngine
+    from oracle import pnp_oracle as O
+    n, h, w = 64, 256, 256
+    data = synthetic.make_problem(n, h, w, accel=4.0, seed=1234)
+    mu_tab, sg_tab = synthetic.param_table(n, 2, seed=77)
+    env = _env(denoiser)
+    st = env.reset(_mat(data), "cuda")
+    for t in range(2):
+        st, done = env.step(st, {"T": torch.zeros(n), "mu": torch.from_numpy(mu_tab[:, t].copy()),
+                                 "sigma_d": torch.from_numpy(sg_tab[:, t].copy())})
+    x = st["x"]
+    assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0     # clamp (noise.py:164)
+    # the dual residual identity of the update u' = u + x - z (env.py:93), starting from u = 0:
+    # after step t:  u_t = u_{t-1} + x_t - z_t  -> check with one more step
+    u_prev = st["u"].clone()
+    st, _ = env.step(st, {"T": torch.zeros(n), "mu": torch.full((n,), 0.3), "sigma_d": torch.full((n,), 0.05)})
+    resid = (st["u"] - (u_prev + st["x"] - st["z"])).abs().max()
+    assert float(resid) < 1e-5
+    # data consistency: on sampled k-space bins, fft_c(z) = (mu*fft_c(x+u_prev) + y0)/(1+mu)
+    from dt4image_restoration_amd.transformations import fft
+    lhs = fft(st["z"][:4].contiguous())
+    rhs_all = fft((st["x"][:4] + u_prev[:4]).contiguous())
+    y0 = st["y0"][:4]
+    m = st["mask"].reshape(1, 1, h, w)
+    want = torch.where(m, (0.3 * rhs_all + y0) / 1.3, rhs_all)
+    assert float((lhs - want).abs().max()) < 2e-5
+    # slices 0 and 63 of the batch == the same slices run alone in a batch-2 engine, bit for bit
+    sel = [0, 63]
+    env2 = _env(denoiser)
+    d2 = {k: (v[sel] if k != "mask" else v) for k, v in data.items()}
+    st2 = env2.reset(_mat(d2), "cuda")
+    for t in range(2):
+        st2, _ = env2.step(st2, {"T": torch.zeros(2), "mu": torch.from_numpy(mu_tab[sel, t].copy()),
+                                 "sigma_d": torch.from_numpy(sg_tab[sel, t].copy())})
+    st2, _ = env2.step(st2, {"T": torch.zeros(2), "mu": torch.full((2,), 0.3), "sigma_d": torch.full((2,), 0.05)})
+    for k in ("x", "z", "u"):
+        assert torch.equal(st[k][sel], st2[k]), k
+    # and one slice against the CPU oracle after the same 3 iterations: PSNR within tolerance
+    sd = O.torch_weights(denoiser.weights)
+    d1 = {k: (v[:1] if k != "mask" else v) for k, v in data.items()}
+    so = O.reset(d1)
+    for t in range(2):
+        so, _ = O.admm_step(sd, so, torch.from_numpy(mu_tab[:1, t].copy()), torch.from_numpy(sg_tab[:1, t].copy()))
+    so, _ = O.admm_step(sd, so, torch.tensor([0.3]), torch.tensor([0.05]))
+    dp = abs(float(O.psnr(so["x"], so["gt"])) - float(env.compute_reward(st["x"][:1], st["gt"][:1])))
+    assert dp < PSNR_TOL_DB
+    np.testing.assert_allclose(st["x"][:1].cpu().numpy(), so["x"].numpy(), rtol=0, atol=2e-5)
