@@ -84,8 +84,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-slices", type=int, default=8)
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-slices", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--dump-layers", default=None, help="write the per-layer kernel time table (JSON) here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +178,16 @@ def main():
                                               if k not in ("layers", "conv3x3_mfma")},
             },
         }
+        if args.dump_layers:
+            rows = []
+            for l, ms, cnt in zip(unet_spec.UNET_LAYERS, prof["layers"]["ms"], prof["layers"]["launches"]):
+                fl = 2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * n
+                per = ms / max(cnt, 1)
+                rows.append({"layer": l.key, "cin": l.cin, "cout": l.cout, "hw": [h >> l.level, w >> l.level],
+                             "gflop": round(fl / 1e9, 2), "ms": round(per, 4),
+                             "tflops": round(fl / (per * 1e-3) / 1e12, 2) if per > 0 else None})
+            with open(args.dump_layers, "w") as f:
+                json.dump(rows, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             mu_c, sg_c = synthetic.param_table(n, total_iters, seed=77)
             cb, cdata, chist = cpu_baseline(sd_np, h, w, n, args.cpu_slices, args.cpu_iters, mu_c, sg_c)

@@ -44,9 +44,9 @@ const LayerSpec kLayers[N_LAYERS] = {
 // ------------------------------------------------------------------------------------------------
 // Weight pack: float4 units [cout/32][cin/32][tap 9][s 4][lane 64]; lane l (n = l&31, hh = l>>5) holds
 // W[cout = 32*cb + n][cin = 32*chunk + 8*s + 4*hh + j][ky][kx], j = 0..3 - the B operand of the j-th
-// MFMA of k-step (chunk, tap, s).  One extra k-step of zeros pads the tail for the prefetch.
+// MFMA of k-step (chunk, tap, s).  Two extra k-steps of zeros pad the tail for the prefetch.
 size_t conv3x3_pack_floats(int cin, int cout) {
-    return (size_t)(cout / 32) * (cin / 32) * 36 * 256 + 256;
+    return (size_t)(cout / 32) * (cin / 32) * 36 * 256 + 512;
 }
 
 void pack_conv3x3_weights(const float* oihw, int cin, int cout, float* dst) {
@@ -62,7 +62,7 @@ void pack_conv3x3_weights(const float* oihw, int cin, int cout, float* dst) {
                             const int ci = 32 * ch + 8 * s + 4 * (l >> 5) + j;
                             dst[o++] = oihw[((size_t)co * cin + ci) * 9 + tap];
                         }
-    for (int i = 0; i < 256; ++i) dst[o++] = 0.f;
+    for (int i = 0; i < 512; ++i) dst[o++] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,9 +164,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    float4 bcur[NT];
+    // B fragments run two k-steps ahead of the MFMAs that consume them (L2 latency ~ one k-step of MFMA time);
+    // the tail of the packed stream is zero-padded by two k-steps so the prefetch never leaves the buffer.
+    float4 b0[NT], b1[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bcur[nt] = bptr[nt][0];
+    for (int nt = 0; nt < NT; ++nt) {
+        b0[nt] = bptr[nt][0];
+        b1[nt] = bptr[nt][64];
+    }
 
     for (int c = 0; c < nchunks; ++c) {
         // ---- stage the halo patch of chunk c (zero outside the image = the conv's zero padding) ----
@@ -198,34 +203,42 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
         }
         __syncthreads();
 
-        // ---- 9 taps x 4 k-steps of 8 channels ----
+        // ---- 9 taps x 4 k-steps of 8 channels, software-pipelined: while the MFMAs of k-step ks issue, the A
+        // fragments of ks+1 (LDS) and the B fragments of ks+2 (L2) are in flight.  The sched_barriers keep hipcc
+        // from sinking the loads down to their first use (it does, and then every k-step waits on L2).
         const float4* bp[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bp[nt] = bptr[nt] + (size_t)c * 36 * 64;
+        float4 a0[MT];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * PW + (tap % 3)) * CKP;
+        for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt]]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ks = tap * 4 + s;
-                float4 bnext[NT];
+        for (int ks = 0; ks < 36; ++ks) {
+            float4 b2[NT], a1[MT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bnext[nt] = bp[nt][(ks + 1) * 64];   // tail is zero-padded
-                float4 av[MT];
+            for (int nt = 0; nt < NT; ++nt) b2[nt] = bp[nt][(ks + 2) * 64];
+            if (ks + 1 < 36) {
+                const int tap1 = (ks + 1) >> 2, s1 = (ks + 1) & 3;
+                const int off1 = ((tap1 / 3) * PW + (tap1 % 3)) * CKP + 8 * s1;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    av[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt] + toff + 8 * s]);
+                for (int mt = 0; mt < MT; ++mt) a1[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt] + off1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bcur[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bcur[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bcur[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bcur[nt].w, acc[mt][nt], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].x, b0[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].y, b0[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].z, b0[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].w, b0[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnext[nt];
+            for (int nt = 0; nt < NT; ++nt) { b0[nt] = b1[nt]; b1[nt] = b2[nt]; }
+            if (ks + 1 < 36) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
             }
         }
     }
