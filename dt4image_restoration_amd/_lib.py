@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpnpadmm.so")
+LIB_PATH = os.environ.get("PNP_LIB_PATH") or os.path.join(_HERE, "csrc", "libpnpadmm.so")   # override: kernel experiments
 
 PNP_FLAG_PROFILE = 1
 PNP_FLAG_NO_DENOISER = 2

@@ -262,7 +262,7 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         } else {
             pf = conv3x3_pack_floats(L.cin, L.cout);
             tmp.resize(pf);
-            pack_conv3x3_weights(w, L.cin, L.cout, tmp.data());
+            pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, e->cfg.h >> L.level, e->cfg.w >> L.level, L.cout).ck, tmp.data());
             src = tmp.data();
         }
         HIP_TRY(hipMalloc((void**)&e->d_wpack[li], pf * sizeof(float)));

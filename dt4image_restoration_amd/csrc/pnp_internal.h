@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 
 namespace pnp {
 
@@ -25,7 +26,7 @@ struct ConvArgs {
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size
     int Cin, Cskip, Cout;
-    int tilesX, tilesY;
+    int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
 };
 
@@ -33,10 +34,20 @@ struct ConvArgs {
 // from W and Cout).  Returns hipSuccess or the launch error.
 hipError_t launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s);
 
-// Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream.
-// dst must hold conv3x3_pack_floats(cin, cout) floats.
+// Tile plan of a conv3x3 launch (picked from the problem size and Cout).
+struct ConvPlan {
+    int tw, th;        // pixel tile
+    int bm, bn;        // pixels / output channels per workgroup tile
+    int mt, nt, wm, wn; // M-/N-blocks (32x32) per wave; wave grid
+    int ck;            // input channels per staged chunk (16 or 32)
+    int tiles_x, tiles_y;
+};
+ConvPlan conv3x3_plan(int N, int H, int W, int Cout);
+
+// Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
+// layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.
 size_t conv3x3_pack_floats(int cin, int cout);
-void pack_conv3x3_weights(const float* oihw, int cin, int cout, float* dst);
+void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* dst);
 
 // First layer (2 -> 32, K = 18: too thin for MFMA, direct VALU) and last layer (1x1 32 -> 1 fused
 // with the residual add and clamp).  `ximg` (f32 [N,H,W]) or, when null, Re(z-u) of complex64 z,u
