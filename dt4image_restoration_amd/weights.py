@@ -109,3 +109,36 @@ def flatten_state_dict(sd: Mapping[str, np.ndarray]) -> np.ndarray:
 def to_torch_state_dict(sd: Mapping[str, np.ndarray]):
     import torch
     return {k: torch.from_numpy(np.array(v, dtype=np.float32, copy=True)) for k, v in sd.items()}
+
+
+def generate_policy_weights(model, seed: int = 0, t_bias: float = 0.0, head_gain: float = 1.0):
+    """Deterministic stand-in for the decision-transformer checkpoints (external downloads): N(0, 0.02)-like
+    weights from the counter hash for every Linear/Embedding/Conv, LayerNorm = (1, 0), biases 0 - the reference's
+    `_init_weights` (decision_transformer.py:157-164) statistics - written into `model.state_dict()` order so the
+    SAME tensors load into the reference's DecisionTransformer.  `t_bias` shifts the stop logit, `head_gain` scales
+    the action head (random heads sit at sigmoid(0) = 0.5, exactly on the stop threshold)."""
+    import torch
+    sd = model.state_dict()
+    out = {}
+    for i, (k, v) in enumerate(sd.items()):
+        if k.endswith("masking"):
+            out[k] = v.clone()
+            continue
+        n = v.numel()
+        if ".ln" in k or k.startswith("layer_n"):
+            arr = np.ones(n, np.float32) if k.endswith("weight") else np.zeros(n, np.float32)
+        elif k.endswith("bias"):
+            arr = np.zeros(n, np.float32)
+        else:
+            u = hash_uniform(seed, 1000 + 2 * i, n).astype(np.float64) + hash_uniform(seed, 1001 + 2 * i, n) + \
+                hash_uniform(seed, 5000 + 2 * i, n)                     # sum of 3 uniforms: var = 1
+            arr = (0.02 * u).astype(np.float32)
+            if k.startswith("state_encoder.0") or k.startswith("state_encoder.2") or k.startswith("state_encoder.4"):
+                arr = (arr * 5.0).astype(np.float32)                    # conv stem: keep the image signal alive
+        out[k] = torch.from_numpy(arr.reshape(tuple(v.shape)).copy())
+    out["predict_action.0.weight"] = out["predict_action.0.weight"] * head_gain
+    order = list(model.action_range.keys())
+    b = out["predict_action.0.bias"].clone()
+    b[order.index("T")] = t_bias
+    out["predict_action.0.bias"] = b
+    return out

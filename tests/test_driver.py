@@ -1,0 +1,152 @@
+"""Greedy decision-transformer driver and the `.mat` evaluation format (8f #2).
+
+G7 (tests/golden/g7_greedy.npz) was produced by the reference's own Evaluator.get_initial_policy_setup + run_greedy with
+its own DecisionTransformer / PnPEnv / U-Net on the CPU.  The CPU tests drive the SAME driver code with an oracle-backed
+env; the GPU test drives it with the HIP PnPEnv."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from dt4image_restoration_amd import data as D, synthetic, weights
+from dt4image_restoration_amd.drivers.greedy import GreedyEvaluator
+from dt4image_restoration_amd.policy import DecisionTransformer, DecisionTransformerConfig, policy_observation
+from oracle import pnp_oracle as O
+
+CASES = ["full30", "stop_now", "stop_mid"]
+
+
+def _policy(cfg):
+    pseed, t_bias, gain = int(cfg[0]), float(cfg[1]), float(cfg[2])
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, pseed, t_bias=t_bias, head_gain=gain))
+    return m
+
+
+class OracleEnv:
+    """PnPEnv-shaped wrapper over the CPU oracle (tests only)."""
+
+    def __init__(self):
+        self.sd = O.torch_weights(weights.generate_unet_weights(0, "unit_gain"))
+
+    def reset(self, mat, device):
+        return O.reset({k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in mat.items()})
+
+    def step(self, st, action):
+        with torch.no_grad():
+            st, done = O.admm_step(self.sd, st, action["mu"], action["sigma_d"], action["T"])
+        return st, done
+
+    def compute_reward(self, x, gt):
+        return O.psnr(x, gt)
+
+
+def test_policy_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_greedy.npz"))
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=0.0, head_gain=12.0))
+    b, t = 2, 6
+    rtg = torch.from_numpy((synthetic.hash_uniform(70, 1, b * t).reshape(b, t, 1) + 1) * 0.5)
+    st = torch.from_numpy((synthetic.hash_uniform(70, 2, b * t * 16384).reshape(b, t, 16384) + 1) * 0.5)
+    ts = torch.arange(t).reshape(1, t, 1).repeat(b, 1, 1)
+    task = torch.tensor([[3], [7]]).repeat(1, t)
+    act = torch.from_numpy((synthetic.hash_uniform(70, 3, b * t * 3).reshape(b, t, 3) + 1) * 0.5)
+    with torch.no_grad():
+        np.testing.assert_allclose(m(rtg, st, ts, task, actions=None)[0].numpy(), g["policy_noact"], atol=1e-6)
+        pa, ad = m(rtg, st, ts, task, act, eval_actions=True)
+        np.testing.assert_allclose(pa.numpy(), g["policy_act"], atol=1e-6)
+        assert list(ad.keys()) == ["T", "sigma_d", "mu"] and float(ad["sigma_d"].max()) <= 70 / 255 + 1e-6
+        np.testing.assert_allclose(m(rtg, st, ts, task, act, eval_rtg=True).numpy(), g["policy_rtg"], atol=1e-6)
+        np.testing.assert_allclose(m(rtg, st, ts, task, act)[0].numpy(), g["policy_train"], atol=1e-6)
+    flex = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=6, mode="flex"))
+    assert list(flex.action_range.keys()) == ["mu", "sigma_d", "T"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_greedy_driver_on_oracle_env_matches_reference_rollout(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "g7_greedy.npz"))
+    cfg = g[f"{case}_cfg"]
+    problem = synthetic.make_problem(1, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    ev = GreedyEvaluator(_policy(cfg), OracleEnv(), max_timesteps=30, block_size=18, device_type="cpu")
+    res = ev.run({k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()},
+                 rtg=torch.tensor([D.normalised_rtg(cfg[3])]), task=torch.tensor([int(cfg[4])]))
+    stop = int(g[f"{case}_time"])
+    assert int(res.stop_time[0]) == stop
+    handed = g[f"{case}_handed"]                      # (T, sigma_d, mu) the reference handed to env.step, per call
+    # actions written before the stop are the same tokens the reference wrote
+    np.testing.assert_allclose(res.actions[0, :min(stop, 30)].numpy(), g[f"{case}_eval_actions"][:min(stop, 30)], atol=2e-5)
+    np.testing.assert_allclose(res.actions[0, :len(handed)].numpy()[:, 0], handed[:, 0], atol=2e-5)
+    assert abs(float(res.reward[0]) - float(g[f"{case}_reward"])) < 1e-3
+    assert abs(float(res.initial_reward[0]) - float(g[f"{case}_old_reward"])) < 1e-4
+    xr = res.x.real if res.x.is_complex() else res.x          # the oracle keeps complex x0 until the first step, like the reference
+    np.testing.assert_allclose(xr.numpy().reshape(128, 128), g[f"{case}_x"].reshape(128, 128), atol=5e-5)
+
+
+def test_policy_observation_downsamples_larger_slices():
+    x = torch.rand(2, 1, 256, 256)
+    ob = policy_observation(x)
+    assert ob.shape == (2, 16384)
+    np.testing.assert_allclose(ob[0].reshape(128, 128)[3, 5], x[0, 0, 6:8, 10:12].mean(), rtol=1e-6)
+    assert torch.equal(policy_observation(torch.ones(1, 1, 128, 128)), torch.ones(1, 16384))
+
+
+def test_mat_round_trip_and_task_tokens(tmp_path):
+    p = synthetic.make_problem(3, 32, 32, seed=8)
+    for i, tag in enumerate(("4_10", "4_10", "8_5")):
+        D.save_mat(str(tmp_path / f"img{i}_{tag}_x.mat"), p, i)
+    batch, tasks = D.load_dir(str(tmp_path))
+    for k in ("x0", "y0", "ATy0", "gt"):
+        assert np.array_equal(batch[k], p[k]) and batch[k].dtype == np.float32
+    assert np.array_equal(batch["mask"], p["mask"])
+    assert tasks == ["4x_10", "4x_10", "8x_5"]
+    assert D.task_tokens(tasks).tolist() == [4, 4, 6]
+    assert D.task_tokens(tasks, flex_target=3.5).tolist() == [2, 2, 2]
+    assert abs(D.normalised_rtg(10.0) - (10 + 1.08) / (16.6 + 1.08)) < 1e-12
+    with pytest.raises(ValueError):
+        D.task_from_filename("no_task_here.mat")
+    with pytest.raises(FileNotFoundError):
+        D.load_dir(str(tmp_path / "nothing") if os.makedirs(tmp_path / "nothing") is None else "")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_greedy_driver_on_hip_env_matches_reference_rollout(golden_dir, case):
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.env import PnPEnv
+    g = np.load(os.path.join(golden_dir, "g7_greedy.npz"))
+    cfg = g[f"{case}_cfg"]
+    problem = synthetic.make_problem(1, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    env = PnPEnv(30, UNetDenoiser2D.seeded(0, "unit_gain"), "cuda")
+    ev = GreedyEvaluator(_policy(cfg), env, max_timesteps=30, block_size=18, device_type="cuda")
+    res = ev.run({k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()},
+                 rtg=torch.tensor([D.normalised_rtg(cfg[3])]), task=torch.tensor([int(cfg[4])]))
+    stop = int(g[f"{case}_time"])
+    assert int(res.stop_time[0]) == stop
+    handed = g[f"{case}_handed"]
+    # FLOAT TOLERANCE: the policy sees the HIP engine's images (f32, ~1e-6 from the reference's); its sigmoid outputs
+    # move by < 1e-4
+    np.testing.assert_allclose(res.actions[0, :len(handed)].numpy()[:, 0], handed[:, 0], atol=2e-4)
+    assert abs(float(res.reward[0]) - float(g[f"{case}_reward"])) < 0.01       # north_star PSNR tolerance
+    np.testing.assert_allclose(res.x.cpu().numpy().reshape(128, 128), g[f"{case}_x"].reshape(128, 128), atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_greedy_batch_equals_single_slice_rollouts():
+    """4 slices with different stop behaviour rolled out as ONE batch == each rolled out alone."""
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=0.0, head_gain=12.0))
+    problem = synthetic.make_problem(4, 128, 128, accel=4.0, seed=77)
+    rtg = torch.tensor([D.normalised_rtg(v) for v in (10.0, 4.0, 14.0, 8.0)])
+    task = torch.tensor([5, 4, 5, 3])
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+    full = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), device_type="cuda").run(mat, rtg, task)
+    for i in range(4):
+        one_mat = {k: (v[i:i + 1] if k != "mask" else v) for k, v in mat.items()}
+        one = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), device_type="cuda").run(one_mat, rtg[i:i + 1], task[i:i + 1])
+        assert int(one.stop_time[0]) == int(full.stop_time[i])
+        assert abs(float(one.reward[0]) - float(full.reward[i])) < 1e-3
