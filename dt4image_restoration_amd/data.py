@@ -20,10 +20,11 @@ _MAT_KEYS = ("x0", "y0", "mask", "ATy0", "gt")
 
 def task_from_filename(fn: str) -> str:
     """`\\d+_\\d+` in the file name -> '<accel>x_<sigma>' (datasets.py:13-16, :188-189)."""
-    m = re.search(r"(\d+)_(\d+)", os.path.basename(fn))
+    m = re.search(r"\d+_\d+", os.path.basename(fn))
     if m is None:
         raise ValueError(f"no '<accel>_<sigma>' task tag in file name {fn!r}")
-    return f"{m.group(1)}x_{m.group(2)}"
+    t = m.group()
+    return t[0] + "x" + t[1:]           # exactly the reference's string surgery (single-digit acceleration)
 
 
 def normalised_rtg(target: float, flex: bool = False) -> float:

@@ -95,7 +95,7 @@ def test_policy_observation_downsamples_larger_slices():
 def test_mat_round_trip_and_task_tokens(tmp_path):
     p = synthetic.make_problem(3, 32, 32, seed=8)
     for i, tag in enumerate(("4_10", "4_10", "8_5")):
-        D.save_mat(str(tmp_path / f"img{i}_{tag}_x.mat"), p, i)
+        D.save_mat(str(tmp_path / f"img{'abc'[i]}_{tag}_x.mat"), p, i)
     batch, tasks = D.load_dir(str(tmp_path))
     for k in ("x0", "y0", "ATy0", "gt"):
         assert np.array_equal(batch[k], p[k]) and batch[k].dtype == np.float32
