@@ -44,20 +44,38 @@ const LayerSpec kLayers[N_LAYERS] = {
 // cannot hide its own LDS/global loads under it, so the k-loop rate is set by loads per MFMA: a 2x1 register
 // tile (MT x NT blocks of 32x32) runs at 74 cycles/MFMA, 2x2 at 69, 4x1 at 67.6, 4x2 at 66.2, 4x4 at 65.0 (64 is
 // the pipe).  So every config uses MT = 4 and the widest NT that Cout and the CU count allow.
-ConvPlan conv3x3_plan(int N, int H, int W, int Cout) {
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout) {
     ConvPlan p{};
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     const long pixels = (long)N * H * W;
     p.mt = 4;
+    p.splitk = 1;
     if (Cout == 32) { p.mt = 2; p.nt = 1; p.wm = 4; p.wn = 1; p.ck = 32; }    // short K, 128-B pixels: small tile, 3 workgroups/CU
     else if (Cout == 64) { p.nt = 2; p.wm = 4; p.wn = 1; p.ck = 16; }
     else if (Cout % 256 == 0 && pixels / 256 * (Cout / 256) >= 256) { p.nt = 4; p.wm = 2; p.wn = 2; p.ck = 32; }
     else { p.nt = 2; p.wm = 2; p.wn = 2; p.ck = 32; }
-    p.bm = p.wm * p.mt * 32;
-    p.bn = p.wn * p.nt * 32;
-    p.th = p.bm / p.tw;
-    p.tiles_x = (W + p.tw - 1) / p.tw;
-    p.tiles_y = (H + p.th - 1) / p.th;
+    auto finish = [&]() {
+        p.bm = p.wm * p.mt * 32;
+        p.bn = p.wn * p.nt * 32;
+        p.th = p.bm / p.tw;
+        p.tiles_x = (W + p.tw - 1) / p.tw;
+        p.tiles_y = (H + p.th - 1) / p.th;
+        return (long)p.tiles_x * p.tiles_y * N * (Cout / p.bn);
+    };
+    long blocks = finish();
+    // Small problems (the reference's own batch-1 128x128 case): the big tiles leave most CUs idle behind a serial
+    // K loop.  Use narrow tiles and cut K into `splitk` ranges of whole chunks, one workgroup each; the partial sums
+    // are combined in a fixed order by splitk_reduce_kernel (bit-reproducible, unlike float atomics).
+    if (blocks < 128 && Cout >= 64) {
+        p.mt = 2; p.nt = 1; p.ck = 32;
+        if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; } else { p.wm = 2; p.wn = 2; }
+        blocks = finish();
+        const int nchunks = Cin / p.ck;
+        int sk = (int)((384 + blocks - 1) / blocks);
+        if (sk > nchunks) sk = nchunks;
+        while (nchunks % sk != 0) --sk;             // equal ranges
+        p.splitk = sk;
+    }
     return p;
 }
 
@@ -148,7 +166,7 @@ __device__ __forceinline__ float4 finish_piece(const ConvArgs& a, int gy, int gx
 //     barrier | registers -> LDS patch (input transform applied) | barrier | issue next chunk's loads | k-loop
 // The next chunk's global loads are issued BEFORE the k-loop and consumed after it, so HBM latency sits under
 // thousands of MFMA cycles; 2-3 workgroups per CU cover each other's barriers, LDS writes and epilogues.
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS>
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK>
 __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int CKP = CK + 4;        // padded pixel stride in LDS (floats): b128 lane groups hit 16 distinct slots
     constexpr int KS = 9 * (CK / 8);   // k-steps (of 8 channels) per chunk
@@ -185,7 +203,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     const int cbt = blockIdx.y;
     if (a.tact != nullptr && a.tact[n] > 0.5f) return;   // slice is done: leave its planes untouched
 
-    const int nchunks = a.Cin / CK;
+    const int nchunks_all = a.Cin / CK;
+    const int cpb = SPLITK ? nchunks_all / (int)gridDim.z : nchunks_all;   // chunks per workgroup
+    const int c_begin = SPLITK ? (int)blockIdx.z * cpb : 0;
+    const int c_end = c_begin + cpb;
 
     // ---- staging helpers ------------------------------------------------------------------------------------
     RawPiece<SRC> raw[PREFETCH ? NIT : LB];
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     };
 
-    if (PREFETCH) issue(0, 0, NIT);
+    if (PREFETCH) issue(c_begin, 0, NIT);
 
     // LDS float offset of this lane's A row for each of its M-blocks (tap (0,0), channel 4*hh)
     int aoff[MT];
@@ -230,8 +251,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cb = cbt * (WN * NT) + wn * NT + nt;
-        bptr[nt] = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * nchunks * KS * 64 + lane;
-        const float bias = a.bias[cb * 32 + li];                   // accumulators start at the bias
+        bptr[nt] = reinterpret_cast<const float4*>(a.wpack) + ((size_t)cb * nchunks_all + c_begin) * KS * 64 + lane;
+        const float bias = SPLITK ? 0.f : a.bias[cb * 32 + li];    // accumulators start at the bias
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -246,8 +267,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bq[p][nt] = bptr[nt][p * 64];
 
-    for (int c = 0; c < nchunks; ++c) {
-        if (c > 0) __syncthreads();            // every wave is done reading the previous chunk's patch
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin) __syncthreads();      // every wave is done reading the previous chunk's patch
         if (PREFETCH) {
             commit(c, 0, NIT);
         } else {
@@ -255,11 +276,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
         __syncthreads();
-        if (PREFETCH && c + 1 < nchunks) issue(c + 1, 0, NIT);
+        if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT);
 
         const float4* bp[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bp[nt] = bptr[nt] + (size_t)c * KS * 64;
+        for (int nt = 0; nt < NT; ++nt) bp[nt] = bptr[nt] + (size_t)(c - c_begin) * KS * 64;
         float4 a0[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt]]);
@@ -293,9 +314,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     }
 
     // ---- epilogue: LeakyReLU(0.2), NHWC store: two full 128-B lines per store instruction; per-slot address
-    // part in the scalar offset of a buffer store, per-lane part in one VGPR per N-block
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dst, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * sizeof(float)), 0x00020000);
+    // part in the scalar offset of a buffer store, per-lane part in one VGPR per N-block.  Split-K workgroups store
+    // their raw partial sums to plane blockIdx.z of the workspace instead.
+    const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
+    float* const obuf = SPLITK ? a.partial + (size_t)blockIdx.z * plane : a.dst;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obuf, 0, (int)(plane * sizeof(float)), 0x00020000);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
@@ -307,48 +330,82 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
                 const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
                 const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
                 const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
-                const float v = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                const float v = SPLITK ? acc[mt][nt][r] : fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
                 if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
             }
     }
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC>
+// out = LeakyReLU(bias + sum_z partial[z]) in a fixed order: the split-K combine.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ dst, const float* __restrict__ tact,
+                                                            size_t plane4, int splitk, int cout4, size_t slice4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane4; i += (size_t)gridDim.x * 256) {
+        if (tact != nullptr && tact[i / slice4] > 0.5f) continue;
+        float4 s = reinterpret_cast<const float4*>(bias)[i % cout4];
+        for (int z = 0; z < splitk; ++z) {
+            const float4 p = reinterpret_cast<const float4*>(partial)[(size_t)z * plane4 + i];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        s.x = fmaxf(s.x, kLeaky * s.x); s.y = fmaxf(s.y, kLeaky * s.y);
+        s.z = fmaxf(s.z, kLeaky * s.z); s.w = fmaxf(s.w, kLeaky * s.w);
+        reinterpret_cast<float4*>(dst)[i] = s;
+    }
+}
+
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK>
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
     constexpr int WPS = MT * NT <= 2 ? 3 : (MT * NT <= 8 ? 2 : 1);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn));
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS>), grid, dim3(256), 0, s, a);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK>
+template <int TW, int MT, int NT, int WM, int WN, int CK, bool SPLITK>
 static hipError_t launch_cfg(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
     switch (src_mode) {
-        case SRC_PLAIN: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_PLAIN>(a, p, s);
-        case SRC_POOL:  return launch_inst<TW, MT, NT, WM, WN, CK, SRC_POOL>(a, p, s);
-        case SRC_UPCAT: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_UPCAT>(a, p, s);
+        case SRC_PLAIN: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_PLAIN, SPLITK>(a, p, s);
+        case SRC_POOL:  return launch_inst<TW, MT, NT, WM, WN, CK, SRC_POOL, SPLITK>(a, p, s);
+        case SRC_UPCAT: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_UPCAT, SPLITK>(a, p, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int TW>
 static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
-    if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32>(a, p, src_mode, s);
-    if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16>(a, p, src_mode, s);
-    if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32>(a, p, src_mode, s);
-    return launch_cfg<TW, 4, 4, 2, 2, 32>(a, p, src_mode, s);
+    if (p.mt == 2 && p.wn == 4) return launch_cfg<TW, 2, 1, 1, 4, 32, true>(a, p, src_mode, s);    // small problems
+    if (p.mt == 2 && p.wn == 2) return launch_cfg<TW, 2, 1, 2, 2, 32, true>(a, p, src_mode, s);
+    if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32, false>(a, p, src_mode, s);
+    if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16, false>(a, p, src_mode, s);
+    if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32, false>(a, p, src_mode, s);
+    return launch_cfg<TW, 4, 4, 2, 2, 32, false>(a, p, src_mode, s);
 }
 
 hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
     if (a0.Cin % 32 != 0 || a0.Cout % 32 != 0 || (a0.Cout > 64 && a0.Cout % 128 != 0)) return hipErrorInvalidValue;
-    const ConvPlan p = conv3x3_plan(a0.N, a0.H, a0.W, a0.Cout);
+    const ConvPlan p = conv3x3_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout);
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
-    if (p.tw == 32) return launch_tw<32>(a, p, src_mode, s);
-    if (p.tw == 16) return launch_tw<16>(a, p, src_mode, s);
-    return launch_tw<8>(a, p, src_mode, s);
+    const bool split = p.mt == 2 && p.wn >= 2;           // the small-problem configs always go through the workspace
+    if (split && a.partial == nullptr) return hipErrorInvalidValue;
+    hipError_t e;
+    if (p.tw == 32) e = launch_tw<32>(a, p, src_mode, s);
+    else if (p.tw == 16) e = launch_tw<16>(a, p, src_mode, s);
+    else e = launch_tw<8>(a, p, src_mode, s);
+    if (e != hipSuccess || !split) return e;
+    const size_t plane4 = (size_t)a.N * a.H * a.W * a.Cout / 4;
+    unsigned blocks = (unsigned)((plane4 + 255) / 256);
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bias, a.dst, a.tact, plane4,
+                       p.splitk, a.Cout / 4, (size_t)a.H * a.W * a.Cout / 4);
+    return hipGetLastError();
+}
+
+size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout) {
+    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout);
+    return (p.mt == 2 && p.wn >= 2) ? (size_t)p.splitk * N * H * W * Cout : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

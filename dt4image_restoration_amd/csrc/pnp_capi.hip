@@ -56,6 +56,7 @@ struct pnp_engine {
     float* d_wpack[N_LAYERS] = {};   // packed conv3x3 weights (layers 1..26), raw for 0 and 27
     float* d_bias[N_LAYERS] = {};
     LevelBufs lv[5] = {};
+    float* d_partial = nullptr;      // split-K workspace (small problems)
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
@@ -121,7 +122,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
     auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl) -> int {
         const LayerSpec& L = kLayers[li];
         ConvArgs a{};
-        a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.tact = tact;
+        a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
             const int hs = a.H / 2, ws = a.W / 2;
@@ -211,6 +212,18 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
             e->ws_bytes += bytes;
         }
     }
+    if (!(cfg->flags & PNP_FLAG_NO_DENOISER)) {
+        size_t pf = 0;
+        for (int li = 1; li < N_LAYERS - 1; ++li) {
+            const LayerSpec& L = kLayers[li];
+            const size_t f = conv3x3_partial_floats(cfg->n, cfg->h >> L.level, cfg->w >> L.level, L.cin, L.cout);
+            if (f > pf) pf = f;
+        }
+        if (pf > 0) {
+            if (hipMalloc((void**)&e->d_partial, pf * sizeof(float)) != hipSuccess) { pnp_destroy(e); return fail(PNP_ERR_NOMEM, "split-K workspace"); }
+            e->ws_bytes += pf * sizeof(float);
+        }
+    }
     const size_t cbytes = N * H * W * sizeof(float2);
     if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||
         hipMalloc((void**)&e->d_masks, N * H * W) != hipSuccess) {
@@ -230,7 +243,7 @@ int pnp_destroy(pnp_handle e) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
     for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); }
-    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks);
+    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial);
     (void)hipFree(e->plan.tw_h); (void)hipFree(e->plan.tw_w);
     for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete e;
@@ -262,7 +275,7 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         } else {
             pf = conv3x3_pack_floats(L.cin, L.cout);
             tmp.resize(pf);
-            pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, e->cfg.h >> L.level, e->cfg.w >> L.level, L.cout).ck, tmp.data());
+            pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, e->cfg.h >> L.level, e->cfg.w >> L.level, L.cin, L.cout).ck, tmp.data());
             src = tmp.data();
         }
         HIP_TRY(hipMalloc((void**)&e->d_wpack[li], pf * sizeof(float)));

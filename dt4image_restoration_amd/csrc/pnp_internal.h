@@ -23,6 +23,7 @@ struct ConvArgs {
     const float* wpack;  // packed weights, see pack_conv3x3_weights()
     const float* bias;   // [Cout]
     float* dst;          // [N,H,W,Cout]
+    float* partial;      // split-K workspace, conv3x3_partial_floats() floats (small problems only)
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size
     int Cin, Cskip, Cout;
@@ -40,9 +41,11 @@ struct ConvPlan {
     int bm, bn;        // pixels / output channels per workgroup tile
     int mt, nt, wm, wn; // M-/N-blocks (32x32) per wave; wave grid
     int ck;            // input channels per staged chunk (16 or 32)
+    int splitk;        // K ranges (of whole chunks), one workgroup each; > 1 only on small problems
     int tiles_x, tiles_y;
 };
-ConvPlan conv3x3_plan(int N, int H, int W, int Cout);
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout);
+size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout);
 
 // Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
 // layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.
