@@ -55,9 +55,11 @@ class GreedyEvaluator:
         pred_actions, action_dict = self.model(er[:, :ctx], es[:, :ctx], et[:, :ctx], ek[:, :ctx], actions=None)
         action, pa = self._pick(action_dict, pred_actions, 0)
         ea[:, 0] = pa
-        # eval.py:90-95 hands the model the rtg/action at INDEX ctx (zeros) for every position of the window
-        zeros_r = er[:, ctx:ctx + 1].expand(-1, ctx, -1)
-        zeros_a = ea[:, ctx:ctx + 1].expand(-1, ctx, -1)
+        # eval.py:90-95 hands the model the rtg/action at INDEX ctx - still all zeros at this point - which the model
+        # broadcasts over every position of the window
+        w = min(ctx, es.shape[1])
+        zeros_r = torch.zeros_like(er[:, :w])
+        zeros_a = torch.zeros_like(ea[:, :w])
         pred_rtg = self.model(zeros_r, es[:, :ctx], et[:, :ctx], ek[:, :ctx], zeros_a, eval_rtg=True)
         return action, pred_rtg[:, 0]
 
@@ -75,34 +77,27 @@ class GreedyEvaluator:
         return action, pred_rtg[:, rtg_pos]
 
     # ---- rollout ---------------------------------------------------------------------------------------------
-    def run(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
-            first_state: Optional[torch.Tensor] = None) -> GreedyResult:
-        """mat: collated `.mat` dict (x0, y0, ATy0, mask, gt); rtg [N] normalised return-to-go target;
-        task [N] int task token; first_state [N, H*W] (default Re x0, datasets.py:162-163)."""
-        dev, T, ctx = self.device, self.max_timesteps, self.context_length
-        states = self.env.reset(mat, dev)
-        n = states["z"].shape[0]
-        if first_state is None:
-            first_state = states["x"]
-        if first_state.is_complex():
-            first_state = first_state.real
+    def buffers(self, n: int, task: torch.Tensor):
+        """Zeroed context buffers (eval.py:65-70): states [n,T,16384], actions [n,T,3], rtg [n,T,1], timesteps, task."""
+        dev, T = self.device, self.max_timesteps
         es = torch.zeros((n, T, 128 * 128), device=dev)
         ea = torch.zeros((n, T, self.action_dim), device=dev)
         er = torch.zeros((n, T, 1), device=dev)
         et = torch.arange(T, device=dev).reshape(1, T, 1).expand(n, -1, -1).contiguous()
         ek = task.reshape(n, 1).to(dev).expand(-1, T).contiguous()
-        es[:, 0] = policy_observation(first_state.to(dev).float().reshape(n, 1, *states["z"].shape[-2:]))
-        er[:, 0, 0] = rtg.reshape(n).to(dev).float()
+        return es, ea, er, et, ek
 
-        initial_reward = self.env.compute_reward(states["x"], states["gt"])
-        action, pred_rtg = self._initial(es, ea, er, et, ek)
+    def rollout(self, states, action, pred_rtg, start_time: int, es, ea, er, et, ek, scorer=None):
+        """eval.py:189-220 from `start_time`: step, observe, re-plan, until every slice stopped or max_timesteps.
+        Returns (reward [N,1] CPU, stop_time [N]).  `scorer(states) -> [N]` replaces PSNR (no-reference rollouts)."""
+        dev, T = self.device, self.max_timesteps
+        n = states["z"].shape[0]
         stopped = torch.zeros(n, dtype=torch.bool, device=dev)
         stop_time = torch.full((n,), T, dtype=torch.int64, device=dev)
-        for time in range(1, T + 1):
+        for time in range(start_time, T + 1):
             states, done = self.env.step(states, action)
             done = torch.as_tensor(done, device=dev).reshape(-1)
-            newly = done & ~stopped
-            stop_time[newly] = time
+            stop_time[done & ~stopped] = time
             stopped |= done
             if time == T or bool(stopped.all()):
                 break
@@ -114,6 +109,28 @@ class GreedyEvaluator:
             for k in action:                                   # stopped slices keep the action that stopped them
                 action[k] = torch.where(live, new_action[k], action[k])
             pred_rtg = torch.where(live.reshape(n, 1), new_rtg, pred_rtg)
-        reward = self.env.compute_reward(states["x"], states["gt"])
-        return GreedyResult(reward=reward, initial_reward=initial_reward, stop_time=stop_time.cpu(),
+        if scorer is not None:
+            reward = torch.as_tensor(scorer(states)).reshape(n, 1).float().cpu()
+        else:
+            reward = self.env.compute_reward(states["x"], states["gt"])
+        return reward, stop_time.cpu()
+
+    def run(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
+            first_state: Optional[torch.Tensor] = None) -> GreedyResult:
+        """mat: collated `.mat` dict (x0, y0, ATy0, mask, gt); rtg [N] normalised return-to-go target;
+        task [N] int task token; first_state [N, H*W] (default Re x0, datasets.py:162-163)."""
+        dev = self.device
+        states = self.env.reset(mat, dev)
+        n = states["z"].shape[0]
+        if first_state is None:
+            first_state = states["x"]
+        if first_state.is_complex():
+            first_state = first_state.real
+        es, ea, er, et, ek = self.buffers(n, task)
+        es[:, 0] = policy_observation(first_state.to(dev).float().reshape(n, 1, *states["z"].shape[-2:]))
+        er[:, 0, 0] = rtg.reshape(n).to(dev).float()
+        initial_reward = self.env.compute_reward(states["x"], states["gt"])
+        action, pred_rtg = self._initial(es, ea, er, et, ek)
+        reward, stop_time = self.rollout(states, action, pred_rtg, 1, es, ea, er, et, ek)
+        return GreedyResult(reward=reward, initial_reward=initial_reward, stop_time=stop_time,
                             actions=ea.cpu(), x=states["x"])

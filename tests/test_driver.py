@@ -150,3 +150,64 @@ def test_greedy_batch_equals_single_slice_rollouts():
         one = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), device_type="cuda").run(one_mat, rtg[i:i + 1], task[i:i + 1])
         assert int(one.stop_time[0]) == int(full.stop_time[i])
         assert abs(float(one.reward[0]) - float(full.reward[i])) < 1e-3
+
+
+@pytest.mark.gpu
+def test_mcts_mechanics_with_stub_scorer():
+    """Tree mechanics with a deterministic positive scorer (smoothness of x; ARNIQA scores are positive too and the
+    reference's max-backup starts from reward 0) and a fixed sampling seed: reproducible, the
+    tree grows by n_children per expanded node, rewards back up as maxima, snapshots are not aliased."""
+    import torch.nn.functional as F
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.drivers.mcts import MCTS, select_p_ucb
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=12.0))
+
+    def scorer(states):
+        x = states["x"]
+        return 1.0 / (1e-3 + ((x - F.avg_pool2d(x, 3, 1, 1)) ** 2).mean(dim=(1, 2, 3)))
+
+    problem = synthetic.make_problem(1, 128, 128, accel=4.0, seed=5)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+
+    def search(seed):
+        ev = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), max_timesteps=8, device_type="cuda")
+        return MCTS(ev, scorer, n_children=3, rounds=4, seed=seed).run(mat, torch.tensor([D.normalised_rtg(10.0)]),
+                                                                      torch.tensor([4]))
+    p1, root1 = search(3)
+    p2, root2 = search(3)
+    assert float(p1) == float(p2)                                  # seeded -> reproducible
+    assert len(root1.children) == 3 and root1.visits == 4
+    n_nodes, stack = 0, [root1]
+    while stack:
+        nd = stack.pop()
+        n_nodes += 1
+        stack += nd.children
+        for c in nd.children:
+            assert c.time == nd.time + 1 and c.reward <= nd.reward + 1e-12       # max-backup
+            assert c.snap["x"].data_ptr() != nd.snap["x"].data_ptr()            # no aliasing of node states
+    assert n_nodes == 1 + 3 * 4                                                  # one expansion per round
+    assert 15.0 < float(p1) < 45.0
+    assert select_p_ucb(root1, root1.children) in root1.children
+
+
+@pytest.mark.gpu
+def test_cli_subcommands_run_on_synthetic_data():
+    from dt4image_restoration_amd import cli
+    ev = cli.main(["--block_size", "18", "--n_embeds", "9", "--limit", "2", "eval", "--rtg", "10", "--max_timesteps", "5"])
+    assert len(ev) == 2 and all(20 < e["psnr"] < 45 and e["n"] == 2 for e in ev)
+    fx = cli.main(["--block_size", "18", "--n_embeds", "6", "--limit", "2", "flex", "--max_timesteps", "3"])
+    assert [f["rtg_target"] for f in fx] == [1.5, 3, 3.5, 4, 4.5]
+    mc = cli.main(["--block_size", "18", "--n_embeds", "9", "--limit", "1", "mcts", "--rtg", "5", "--max_timesteps", "4",
+                   "--rollouts", "2"])
+    assert len(mc) == 2 and all("mcts_psnr" in m for m in mc)
+
+
+def test_cli_rejects_train_and_requires_mode():
+    from dt4image_restoration_amd import cli
+    with pytest.raises(SystemExit):
+        cli.main(["--block_size", "18", "--n_embeds", "9", "train"])
+    with pytest.raises(SystemExit):
+        cli.main(["--block_size", "18", "--n_embeds", "9"])
