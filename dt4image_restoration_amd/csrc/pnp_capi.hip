@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,7 @@ struct pnp_engine {
     float* d_bias[N_LAYERS] = {};
     LevelBufs lv[5] = {};
     float* d_partial = nullptr;      // split-K workspace (small problems)
+    bool wino[N_LAYERS] = {};         // layer runs on the Winograd kernel (weights packed for it)
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
@@ -130,7 +132,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
             a.rw = a.W > 1 ? (float)(ws - 1) / (float)(a.W - 1) : 0.f;
         }
         Prof p(e, s, 0, li);
-        HIP_TRY(launch_conv3x3(a, L.src, s));
+        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, L.src, s));
+        else HIP_TRY(launch_conv3x3(a, L.src, s));
         return PNP_OK;
     };
     int rc;
@@ -273,9 +276,18 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         if (li == 0 || li == N_LAYERS - 1) {   // first (2->32, OIHW as is) and last (1x1) layers
             pf = nw; src = w;
         } else {
-            pf = conv3x3_pack_floats(L.cin, L.cout);
-            tmp.resize(pf);
-            pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, e->cfg.h >> L.level, e->cfg.w >> L.level, L.cin, L.cout).ck, tmp.data());
+            const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
+            const WinoPlan wp = winograd_plan(e->cfg.n, lh, lw, L.cin, L.cout);
+            e->wino[li] = wp.use && getenv("PNP_NO_WINOGRAD") == nullptr;
+            if (e->wino[li]) {
+                pf = winograd_pack_floats(L.cin, L.cout);
+                tmp.resize(pf);
+                pack_winograd_weights(w, L.cin, L.cout, wp.ck, tmp.data());
+            } else {
+                pf = conv3x3_pack_floats(L.cin, L.cout);
+                tmp.resize(pf);
+                pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, lh, lw, L.cin, L.cout).ck, tmp.data());
+            }
             src = tmp.data();
         }
         HIP_TRY(hipMalloc((void**)&e->d_wpack[li], pf * sizeof(float)));

@@ -52,6 +52,16 @@ size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout);
 size_t conv3x3_pack_floats(int cin, int cout);
 void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* dst);
 
+// Winograd F(2x2,3x3) path for the K-heavy layers (winograd_kernels.hip).
+struct WinoPlan {
+    bool use;          // layer is eligible (long K, enough workgroups)
+    int tw, th, bn, wm, wn, ck, tiles_x, tiles_y;
+};
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout);
+size_t winograd_pack_floats(int cin, int cout);
+void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* dst);
+hipError_t launch_conv3x3_winograd(const ConvArgs& a, int src_mode, hipStream_t s);
+
 // First layer (2 -> 32, K = 18: too thin for MFMA, direct VALU) and last layer (1x1 32 -> 1 fused
 // with the residual add and clamp).  `ximg` (f32 [N,H,W]) or, when null, Re(z-u) of complex64 z,u
 // is the image channel.

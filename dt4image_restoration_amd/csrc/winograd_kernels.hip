@@ -1,0 +1,289 @@
+// Winograd F(2x2, 3x3) convolution for the K-heavy denoiser layers on gfx950 (MI355X).
+//
+// Same operator as conv3x3_mfma_kernel (conv3x3 s1 p1 + bias + LeakyReLU(0.2), /root/reference/evaluation/noise.py:75-98,
+// with the stage's MaxPool / bilinear-upsample+concat input transform applied while staging), computed with the
+// minimal-filtering identity  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 2x2 output tile: 16 multiplies per tile and
+// (cin, cout) pair instead of 36, i.e. 2.25x fewer MFMAs, in exact f32 MFMA arithmetic (coefficients 1, 1/2, 1/4).
+// The f32 matrix pipe is the bound of the direct kernel (124 TF/s = 79 % of peak), so fewer MFMAs is the lever left.
+//
+// Workgroup = 4 waves = WM groups of 32 tiles x WN groups of 32 output channels.  Per CK-channel chunk:
+//   1. stage the (TH+2) x (TW+2) halo patch in LDS (same code path and input transforms as the direct kernel)
+//   2. input transform: thread (tile, 4 channels) reads its 4x4 window from the patch, V = B^T d B, writes the 16
+//      frequency planes V[xi][tile][channel] to LDS
+//   3. 16 independent GEMMs: for every frequency xi, acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment,
+//      transformed weights streamed from L2 in pre-packed per-lane order, 4 pairs ahead)
+// All 16 accumulators of a (tile, channel) element live in one lane, so the output transform Y = A^T M A, bias,
+// LeakyReLU and the NHWC stores are lane-local.  256 accumulator registers per lane => one wave per SIMD.
+#include "pnp_internal.h"
+#include "conv_staging.h"
+
+namespace pnp {
+
+// ---- host: U = G g G^T, packed [cout/32][chunk][ks][xi][lane][4] like the direct kernel's B stream ---------------
+size_t winograd_pack_floats(int cin, int cout) { return (size_t)(cout / 32) * (cin / 8) * 16 * 256 + 4 * 256; }
+
+void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* dst) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> U((size_t)cout * cin * 16);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = oihw + ((size_t)co * cin + ci) * 9;
+            double t[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[kx] + G[i][1] * g[3 + kx] + G[i][2] * g[6 + kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    U[((size_t)co * cin + ci) * 16 + 4 * i + j] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+    size_t o = 0;
+    for (int cb = 0; cb < cout / 32; ++cb)
+        for (int ch = 0; ch < cin / ck; ++ch)
+            for (int ks = 0; ks < ck / 8; ++ks)
+                for (int xi = 0; xi < 16; ++xi)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = 32 * cb + (l & 31);
+                            const int ci = ck * ch + 8 * ks + 4 * (l >> 5) + j;
+                            dst[o++] = U[((size_t)co * cin + ci) * 16 + xi];
+                        }
+    for (int i = 0; i < 4 * 256; ++i) dst[o++] = 0.f;
+}
+
+// Eligibility + tile plan.  The transforms and the 16-accumulator epilogue are per-item overhead that only long K
+// amortises; short-K layers (Cin < 64) and small problems stay on the direct kernel.
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
+    WinoPlan p{};
+    p.use = false;
+    if (Cin < 64 || Cout < 64 || Cin % 32 || Cout % 64) return p;
+    p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+    if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; p.ck = 32; } else { p.wm = 2; p.wn = 2; p.ck = 16; }
+    const int tc = p.tw / 2, tr = 32 / tc;
+    p.th = p.wm * 2 * tr;
+    p.bn = p.wn * 32;
+    p.tiles_x = (W + p.tw - 1) / p.tw;
+    p.tiles_y = (H + p.th - 1) / p.th;
+    const long blocks = (long)p.tiles_x * p.tiles_y * N * (Cout / p.bn);
+    p.use = blocks >= 192;
+    return p;
+}
+
+template <int TW, int WM, int WN, int CK, int SRC>
+__global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs a) {
+    constexpr int CKP = CK + 4;
+    constexpr int PPP = CK / 4;
+    constexpr int TC = TW / 2, TR = 32 / TC;   // tiles per row / rows of tiles in one 32-tile M-block
+    constexpr int TH = WM * 2 * TR;
+    constexpr int NTILES = WM * 32;
+    constexpr int PWL = TW + 2, PH = TH + 2, PW = PWL;
+    constexpr int ITEMS = PH * PWL * PPP;
+    constexpr int NIT = (ITEMS + 255) / 256;
+    constexpr bool PREFETCH = SRC == SRC_PLAIN;
+    constexpr int LB = PREFETCH ? NIT : (NIT < 3 ? NIT : 3);
+    constexpr int KSC = CK / 8;                // k-steps per chunk
+    constexpr int PAIRS = 16 * KSC;            // (k-step, frequency) pairs per chunk, 4 MFMAs each
+    constexpr int PF = 4;                      // B fragments in flight
+    static_assert(WM * WN == 4 && NTILES * PPP == 256, "one (tile, 4-channel) transform item per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const patch = smem;                             // [PH][PW][CKP]
+    float* const V = smem + PH * PW * CKP;                 // [16][NTILES][CKP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int hh = lane >> 5, li = lane & 31;
+
+    int bt = blockIdx.x;
+    const int tx0 = (bt % a.tilesX) * TW;
+    bt /= a.tilesX;
+    const int ty0 = (bt % a.tilesY) * TH;
+    const int n = bt / a.tilesY;
+    const int cb = blockIdx.y * WN + wn;                   // this wave's 32-channel block
+    if (a.tact != nullptr && a.tact[n] > 0.5f) return;
+    const int nchunks = a.Cin / CK;
+
+    RawPiece<SRC> raw[PREFETCH ? NIT : LB];
+    auto issue = [&](int c, int it0, int cnt) {
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const int idx = tid + (it0 + k) * 256;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PWL, px = pp % PWL;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                issue_piece<SRC>(a, n, gy, gx, c * CK + part * 4, raw[k]);
+        }
+    };
+    auto commit = [&](int c, int it0, int cnt) {
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const int idx = tid + (it0 + k) * 256;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PWL, px = pp % PWL;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
+                *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+            }
+        }
+    };
+    if (PREFETCH) issue(0, 0, NIT);
+
+    // this thread's transform item: tile tq of the workgroup's tile grid (TC wide), channels [4*tg, 4*tg+4)
+    const int tg = tid % PPP, tq = tid / PPP;
+    const int win = ((2 * (tq / TC)) * PW + 2 * (tq % TC)) * CKP + 4 * tg;     // top-left of the 4x4 input window
+    const int vout = tq * CKP + 4 * tg;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+    const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * nchunks * PAIRS * 64 + lane;
+    float4 bq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
+    const int aoff = (wm * 32 + li) * CKP + 4 * hh;        // this lane's row of V[xi]
+
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
+        if (PREFETCH) {
+            commit(c, 0, NIT);
+        } else {
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
+        }
+        __syncthreads();
+        if (PREFETCH && c + 1 < nchunks) issue(c + 1, 0, NIT);
+
+        // ---- input transform V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] ------------------------
+        {
+            float4 t[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 d0 = *reinterpret_cast<const float4*>(&patch[win + (0 * PW + x) * CKP]);
+                const float4 d1 = *reinterpret_cast<const float4*>(&patch[win + (1 * PW + x) * CKP]);
+                const float4 d2 = *reinterpret_cast<const float4*>(&patch[win + (2 * PW + x) * CKP]);
+                const float4 d3 = *reinterpret_cast<const float4*>(&patch[win + (3 * PW + x) * CKP]);
+                t[0][x] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+                t[1][x] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+                t[2][x] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+                t[3][x] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v0 = make_float4(t[i][0].x - t[i][2].x, t[i][0].y - t[i][2].y, t[i][0].z - t[i][2].z, t[i][0].w - t[i][2].w);
+                const float4 v1 = make_float4(t[i][1].x + t[i][2].x, t[i][1].y + t[i][2].y, t[i][1].z + t[i][2].z, t[i][1].w + t[i][2].w);
+                const float4 v2 = make_float4(t[i][2].x - t[i][1].x, t[i][2].y - t[i][1].y, t[i][2].z - t[i][1].z, t[i][2].w - t[i][1].w);
+                const float4 v3 = make_float4(t[i][1].x - t[i][3].x, t[i][1].y - t[i][3].y, t[i][1].z - t[i][3].z, t[i][1].w - t[i][3].w);
+                *reinterpret_cast<float4*>(&V[(4 * i + 0) * NTILES * CKP + vout]) = v0;
+                *reinterpret_cast<float4*>(&V[(4 * i + 1) * NTILES * CKP + vout]) = v1;
+                *reinterpret_cast<float4*>(&V[(4 * i + 2) * NTILES * CKP + vout]) = v2;
+                *reinterpret_cast<float4*>(&V[(4 * i + 3) * NTILES * CKP + vout]) = v3;
+            }
+        }
+        __syncthreads();
+
+        // ---- 16 GEMMs: pair p = (k-step, xi); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair ----
+        const float4* bp = bptr + (size_t)c * PAIRS * 64;
+        float4 a0 = *reinterpret_cast<const float4*>(&V[aoff]);
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+            float4 a1;
+            if (p + 1 < PAIRS) {
+                const int ks1 = (p + 1) / 16, xi1 = (p + 1) % 16;
+                a1 = *reinterpret_cast<const float4*>(&V[xi1 * NTILES * CKP + aoff + 8 * ks1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int xi = p % 16;
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq[p % PF].x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq[p % PF].y, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq[p % PF].z, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq[p % PF].w, acc[xi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
+            if (p + 1 < PAIRS) a0 = a1;
+        }
+    }
+
+    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores ------------------
+    const int co = cb * 32 + li;
+    const float bias = a.bias[co];
+    const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * sizeof(float)), 0x00020000);
+    const int gy_base = ty0 + wm * 2 * TR;
+    const unsigned obase = ((unsigned)(((size_t)n * a.H + gy_base) * a.W + tx0) * (unsigned)a.Cout + (unsigned)co) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;     // tile within the M-block (hh is per lane)
+        // rows of A^T M: s0[j] = M0j + M1j + M2j,  s1[j] = M1j - M2j - M3j
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+            s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2] + bias;
+        y[0][1] = s0[1] - s0[2] - s0[3] + bias;
+        y[1][0] = s1[0] + s1[1] + s1[2] + bias;
+        y[1][1] = s1[1] - s1[2] - s1[3] + bias;
+        const int ty = t / TC, tx = t % TC;                // per-lane (through hh)
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int gy = gy_base + 2 * ty + ya, gx = tx0 + 2 * tx + xb;
+                const float v = fmaxf(y[ya][xb], kLeaky * y[ya][xb]);
+                const unsigned off = obase + (unsigned)((2 * ty + ya) * a.W + 2 * tx + xb) * (unsigned)a.Cout * 4u;
+                if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
+            }
+    }
+}
+
+template <int TW, int WM, int WN, int CK, int SRC>
+static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
+    constexpr int TC = TW / 2, TR = 32 / TC, TH = WM * 2 * TR;
+    constexpr size_t lds = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32) * (CK + 4) * sizeof(float);
+    auto kern = conv3x3_winograd_kernel<TW, WM, WN, CK, SRC>;
+    static bool cap = false;
+    if (!cap) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cap = true;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int TW, int WM, int WN, int CK>
+static hipError_t launch_wino_cfg(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s) {
+    switch (src_mode) {
+        case SRC_PLAIN: return launch_wino_inst<TW, WM, WN, CK, SRC_PLAIN>(a, p, s);
+        case SRC_POOL:  return launch_wino_inst<TW, WM, WN, CK, SRC_POOL>(a, p, s);
+        case SRC_UPCAT: return launch_wino_inst<TW, WM, WN, CK, SRC_UPCAT>(a, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int TW>
+static hipError_t launch_wino_tw(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s) {
+    if (p.wm == 1) return launch_wino_cfg<TW, 1, 4, 32>(a, p, src_mode, s);
+    return launch_wino_cfg<TW, 2, 2, 16>(a, p, src_mode, s);
+}
+
+// `a.wpack` must be the Winograd pack (pack_winograd_weights with the plan's ck).
+hipError_t launch_conv3x3_winograd(const ConvArgs& a0, int src_mode, hipStream_t s) {
+    const WinoPlan p = winograd_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout);
+    if (!p.use) return hipErrorInvalidValue;
+    ConvArgs a = a0;
+    a.tilesX = p.tiles_x;
+    a.tilesY = p.tiles_y;
+    if (p.tw == 32) return launch_wino_tw<32>(a, p, src_mode, s);
+    if (p.tw == 16) return launch_wino_tw<16>(a, p, src_mode, s);
+    return launch_wino_tw<8>(a, p, src_mode, s);
+}
+
+}  // namespace pnp
