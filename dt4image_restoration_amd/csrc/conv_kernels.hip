@@ -250,26 +250,69 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     }
 
-    // ---- epilogue: LeakyReLU(0.2), NHWC store: two full 128-B lines per store instruction; per-slot address
-    // part in the scalar offset of a buffer store, per-lane part in one VGPR per N-block.  Split-K workgroups store
-    // their raw partial sums to plane blockIdx.z of the workspace instead.
-    const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
-    float* const obuf = SPLITK ? a.partial + (size_t)blockIdx.z * plane : a.dst;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obuf, 0, (int)(plane * sizeof(float)), 0x00020000);
+    // ---- epilogue: LeakyReLU(0.2) and NHWC store.
+    constexpr int BN = WN * NT * 32;
+    constexpr int OSTR = BN + 4;
+    constexpr bool LDS_EPI = !SPLITK && (size_t)BM * OSTR <= (size_t)PH * PW * CKP;   // output tile fits in the patch space
+    if constexpr (LDS_EPI) {
+        // Through LDS, so the global stores are 16 B per lane over whole pixels (a 4-B-per-lane store tail is
+        // store-issue-bound) and the 2x2 max-pooled copy for the next stage can be written from the same tile.
+        __syncthreads();                                   // every wave is done reading the last patch
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
-        const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh) * (unsigned)a.Cout + (unsigned)co) * 4u;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
-                const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
-                const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
-                const float v = SPLITK ? acc[mt][nt][r] : fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
-                if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int q = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;   // tile pixel (row-major TH x TW)
+                    patch[q * OSTR + (wn * NT + nt) * 32 + li] = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                }
+        __syncthreads();
+        constexpr int V4 = BN / 4;
+        const int cbase = cbt * BN;
+#pragma unroll 4
+        for (int f = tid; f < BM * V4; f += 256) {
+            const int p = f / V4, c4 = f % V4;
+            const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+            if (gy < a.H && gx < a.W)
+                *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cbase + 4 * c4) =
+                    *reinterpret_cast<const float4*>(&patch[p * OSTR + 4 * c4]);
+        }
+        if (a.pooled != nullptr) {                         // MaxPool2d(2) of this tile for the next stage
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+            for (int f = tid; f < (BM / 4) * V4; f += 256) {
+                const int q = f / V4, c4 = f % V4;
+                const int qy = q / (TW / 2), qx = q % (TW / 2);
+                const int gy = (ty0 >> 1) + qy, gx = (tx0 >> 1) + qx;
+                if (gy < Hp && gx < Wp) {
+                    const float* o = &patch[((2 * qy) * TW + 2 * qx) * OSTR + 4 * c4];
+                    const float4 m = f4max(f4max(*reinterpret_cast<const float4*>(o), *reinterpret_cast<const float4*>(o + OSTR)),
+                                           f4max(*reinterpret_cast<const float4*>(o + TW * OSTR), *reinterpret_cast<const float4*>(o + TW * OSTR + OSTR)));
+                    *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * a.Cout + cbase + 4 * c4) = m;
+                }
             }
+        }
+    } else {
+        // Two full 128-B lines per store instruction; per-slot address part in the scalar offset of a buffer store,
+        // per-lane part in one VGPR per N-block.  Split-K workgroups store raw partial sums to plane blockIdx.z.
+        const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
+        float* const obuf = SPLITK ? a.partial + (size_t)blockIdx.z * plane : a.dst;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obuf, 0, (int)(plane * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
+            const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh) * (unsigned)a.Cout + (unsigned)co) * 4u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
+                    const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
+                    const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
+                    const float v = SPLITK ? acc[mt][nt][r] : fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                    if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                }
+        }
     }
 }
 
@@ -338,6 +381,12 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bias, a.dst, a.tact, plane4,
                        p.splitk, a.Cout / 4, (size_t)a.H * a.W * a.Cout / 4);
     return hipGetLastError();
+}
+
+// The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
+bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout) {
+    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout);
+    return p.splitk == 1 && p.mt == 2 && p.nt == 1 && p.wm == 4;
 }
 
 size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout) {

@@ -44,6 +44,7 @@ struct LevelBufs {
     float* p;  // ping
     float* q;  // pong
     float* s;  // skip / stage output kept for the up path
+    float* pool;  // MaxPool2d(2) of s, written by the kernel that writes s (null if that kernel cannot)
     int c, h, w;
 };
 
@@ -59,6 +60,7 @@ struct pnp_engine {
     LevelBufs lv[5] = {};
     float* d_partial = nullptr;      // split-K workspace (small problems)
     bool wino[N_LAYERS] = {};         // layer runs on the Winograd kernel (weights packed for it)
+    bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
@@ -121,9 +123,11 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         Prof p(e, s, 1, 0);
         HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
     }
-    auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl) -> int {
+    auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl, float* pooled = nullptr,
+                    bool src_is_pooled = false) -> int {
         const LayerSpec& L = kLayers[li];
         ConvArgs a{};
+        a.pooled = pooled;
         a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
@@ -131,21 +135,23 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
             a.rh = a.H > 1 ? (float)(hs - 1) / (float)(a.H - 1) : 0.f;
             a.rw = a.W > 1 ? (float)(ws - 1) / (float)(a.W - 1) : 0.f;
         }
+        const int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
         Prof p(e, s, 0, li);
-        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, L.src, s));
-        else HIP_TRY(launch_conv3x3(a, L.src, s));
+        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, src_mode, s));
+        else HIP_TRY(launch_conv3x3(a, src_mode, s));
         return PNP_OK;
     };
     int rc;
-    // inc
+    // inc; a stage's last conv also writes the 2x2 max-pooled copy the next stage starts from, when its kernel can
     if ((rc = conv(1, e->lv[0].p, nullptr, e->lv[0].q, 0))) return rc;
-    if ((rc = conv(2, e->lv[0].q, nullptr, e->lv[0].s, 0))) return rc;
-    // down1..4: conv-0 pools the previous level's stage output while staging
+    if ((rc = conv(2, e->lv[0].q, nullptr, e->lv[0].s, 0, e->pool_ok[0] ? e->lv[0].pool : nullptr))) return rc;
+    // down1..4: conv-0 reads the pooled copy (or pools the previous stage output while staging)
     for (int k = 1; k <= 4; ++k) {
         const int b = 3 * k;
-        if ((rc = conv(b, e->lv[k - 1].s, nullptr, e->lv[k].p, k))) return rc;
+        const bool pooled_in = e->pool_ok[k - 1];
+        if ((rc = conv(b, pooled_in ? e->lv[k - 1].pool : e->lv[k - 1].s, nullptr, e->lv[k].p, k, nullptr, pooled_in))) return rc;
         if ((rc = conv(b + 1, e->lv[k].p, nullptr, e->lv[k].q, k))) return rc;
-        if ((rc = conv(b + 2, e->lv[k].q, nullptr, e->lv[k].s, k))) return rc;
+        if ((rc = conv(b + 2, e->lv[k].q, nullptr, e->lv[k].s, k, (k < 4 && e->pool_ok[k]) ? e->lv[k].pool : nullptr))) return rc;
     }
     // up1..4: conv-0 reads cat([skip, bilinear_up(low)]) while staging
     const float* low = e->lv[4].s;
@@ -207,9 +213,11 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
         LevelBufs& L = e->lv[k];
         L.c = chan[k]; L.h = (int)(H >> k); L.w = (int)(W >> k);
         if (cfg->flags & PNP_FLAG_NO_DENOISER) continue;   // k-space-only handle: no activation planes
-        const size_t bytes = N * L.h * L.w * L.c * sizeof(float);
-        float** bufs[3] = {&L.p, &L.q, &L.s};
+        const size_t bytes_full = N * L.h * L.w * L.c * sizeof(float);
+        float** bufs[4] = {&L.p, &L.q, &L.s, &L.pool};
         for (auto b : bufs) {
+            const size_t bytes = (b == &L.pool) ? (k < 4 ? bytes_full / 4 : 0) : bytes_full;
+            if (bytes == 0) continue;
             hipError_t er = hipMalloc((void**)b, bytes);
             if (er != hipSuccess) { pnp_destroy(e); return fail(PNP_ERR_NOMEM, "activation planes: %s", hipGetErrorString(er)); }
             e->ws_bytes += bytes;
@@ -245,7 +253,7 @@ int pnp_destroy(pnp_handle e) {
     if (!e) return PNP_OK;
     (void)hipDeviceSynchronize();
     for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
-    for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); }
+    for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); (void)hipFree(L.pool); }
     (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial);
     (void)hipFree(e->plan.tw_h); (void)hipFree(e->plan.tw_w);
     for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -294,6 +302,14 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         HIP_TRY(hipMemcpy(e->d_wpack[li], src, pf * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&e->d_bias[li], L.cout * sizeof(float)));
         HIP_TRY(hipMemcpy(e->d_bias[li], b, L.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // which stage outputs get a pooled copy: the producing conv (layers 2, 5, 8, 11) must run a kernel whose epilogue
+    // goes through LDS - the Winograd kernel, or the direct kernel's Cout = 32 configuration on a large problem
+    for (int k = 0; k < 4; ++k) {
+        const int li = 3 * k + 2;
+        const LayerSpec& L = kLayers[li];
+        const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
+        e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout));
     }
     e->weights_loaded = true;
     return PNP_OK;

@@ -23,6 +23,7 @@ struct ConvArgs {
     const float* wpack;  // packed weights, see pack_conv3x3_weights()
     const float* bias;   // [Cout]
     float* dst;          // [N,H,W,Cout]
+    float* pooled;       // optional: also write MaxPool2d(2) of the output, [N,H/2,W/2,Cout] (H, W even)
     float* partial;      // split-K workspace, conv3x3_partial_floats() floats (small problems only)
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size
@@ -46,6 +47,7 @@ struct ConvPlan {
 };
 ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout);
 size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout);
+bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout);
 
 // Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
 // layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.

@@ -135,10 +135,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     const int vout = tq * CKP + 4 * tg;
 
     f32x16 acc[16];
+    const float bias = a.bias[cb * 32 + li];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[xi][r] = xi == 5 ? bias : 0.f;
 
     const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * nchunks * PAIRS * 64 + lane;
     float4 bq[PF];
@@ -146,16 +147,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
     const int aoff = (wm * 32 + li) * CKP + 4 * hh;        // this lane's row of V[xi]
 
+#ifdef PNP_DIAG
+    long long dg[6] = {0, 0, 0, 0, 0, 0};
+    long long dt = __builtin_amdgcn_s_memtime();
+#define DG(i) { const long long t_ = __builtin_amdgcn_s_memtime(); dg[i] += t_ - dt; dt = t_; }
+#else
+#define DG(i)
+#endif
     for (int c = 0; c < nchunks; ++c) {
         if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
+        DG(0)
         if (PREFETCH) {
             commit(c, 0, NIT);
         } else {
 #pragma unroll 1
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
+        DG(1)
         __syncthreads();
+        DG(0)
         if (PREFETCH && c + 1 < nchunks) issue(c + 1, 0, NIT);
+        DG(2)
 
         // ---- input transform V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] ------------------------
         {
@@ -183,7 +195,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
                 *reinterpret_cast<float4*>(&V[(4 * i + 3) * NTILES * CKP + vout]) = v3;
             }
         }
+        DG(3)
         __syncthreads();
+        DG(0)
 
         // ---- 16 GEMMs: pair p = (k-step, xi); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair ----
         const float4* bp = bptr + (size_t)c * PAIRS * 64;
@@ -205,47 +219,77 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
             bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
             if (p + 1 < PAIRS) a0 = a1;
         }
+        DG(4)
     }
-
-    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores ------------------
-    const int co = cb * 32 + li;
-    const float bias = a.bias[co];
-    const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * sizeof(float)), 0x00020000);
-    const int gy_base = ty0 + wm * 2 * TR;
-    const unsigned obase = ((unsigned)(((size_t)n * a.H + gy_base) * a.W + tx0) * (unsigned)a.Cout + (unsigned)co) * 4u;
+    {
+    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]) + LeakyReLU, lane-local; the results go through
+    // LDS (the V/patch space is free now) so that the global stores are 16 B per lane over whole pixels: a 4-B-per-lane
+    // store tail is store-ISSUE-bound (measured: 19k of 208k cycles per workgroup at 64 stores per wave).
+    // The bias rides in on accumulator xi = (1,1), which enters all four outputs with coefficient +1.
+    constexpr int BN = WN * 32;
+    constexpr int OSTR = BN + 4;                           // floats per pixel row of the LDS output tile
+    float* const otile = smem;                             // [TH*TW][OSTR]
+    __syncthreads();                                       // every wave has left its last MFMA phase: V is free
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;     // tile within the M-block (hh is per lane)
-        // rows of A^T M: s0[j] = M0j + M1j + M2j,  s1[j] = M1j - M2j - M3j
-        float s0[4], s1[4];
+        float s0[4], s1[4];                                // rows of A^T M
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
             s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
         }
         float y[2][2];
-        y[0][0] = s0[0] + s0[1] + s0[2] + bias;
-        y[0][1] = s0[1] - s0[2] - s0[3] + bias;
-        y[1][0] = s1[0] + s1[1] + s1[2] + bias;
-        y[1][1] = s1[1] - s1[2] - s1[3] + bias;
-        const int ty = t / TC, tx = t % TC;                // per-lane (through hh)
+        y[0][0] = s0[0] + s0[1] + s0[2];
+        y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2];
+        y[1][1] = s1[1] - s1[2] - s1[3];
+        const int py = wm * 2 * TR + 2 * (t / TC), px = 2 * (t % TC);
 #pragma unroll
         for (int ya = 0; ya < 2; ++ya)
 #pragma unroll
-            for (int xb = 0; xb < 2; ++xb) {
-                const int gy = gy_base + 2 * ty + ya, gx = tx0 + 2 * tx + xb;
-                const float v = fmaxf(y[ya][xb], kLeaky * y[ya][xb]);
-                const unsigned off = obase + (unsigned)((2 * ty + ya) * a.W + 2 * tx + xb) * (unsigned)a.Cout * 4u;
-                if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
-            }
+            for (int xb = 0; xb < 2; ++xb)
+                otile[((py + ya) * TW + px + xb) * OSTR + wn * 32 + li] = fmaxf(y[ya][xb], kLeaky * y[ya][xb]);
     }
+    __syncthreads();
+    constexpr int V4 = BN / 4;                             // float4 per pixel
+    const int cbase = blockIdx.y * BN;
+#pragma unroll 4
+    for (int f = tid; f < TH * TW * V4; f += 256) {
+        const int p = f / V4, c4 = f % V4;
+        const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+        if (gy < a.H && gx < a.W)
+            *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cbase + 4 * c4) =
+                *reinterpret_cast<const float4*>(&otile[p * OSTR + 4 * c4]);
+    }
+    if (a.pooled != nullptr) {                             // MaxPool2d(2) of this tile for the next stage (noise.py:22-25)
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        for (int f = tid; f < (TH / 2) * (TW / 2) * V4; f += 256) {
+            const int q = f / V4, c4 = f % V4;
+            const int qy = q / (TW / 2), qx = q % (TW / 2);
+            const int gy = (ty0 >> 1) + qy, gx = (tx0 >> 1) + qx;
+            if (gy < Hp && gx < Wp) {
+                const float* o = &otile[((2 * qy) * TW + 2 * qx) * OSTR + 4 * c4];
+                const float4 m = f4max(f4max(*reinterpret_cast<const float4*>(o), *reinterpret_cast<const float4*>(o + OSTR)),
+                                       f4max(*reinterpret_cast<const float4*>(o + TW * OSTR), *reinterpret_cast<const float4*>(o + TW * OSTR + OSTR)));
+                *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * a.Cout + cbase + 4 * c4) = m;
+            }
+        }
+    }
+    }
+#ifdef PNP_DIAG
+    DG(5)
+    if (blockIdx.x == 3 && blockIdx.y == 0 && tid == 0)
+        printf("WINO Cin %d Cout %d chunks %d: barrier %lld commit %lld issue %lld transform %lld mfma %lld epilogue %lld\n", a.Cin, a.Cout, nchunks, dg[0], dg[1], dg[2], dg[3], dg[4], dg[5]);
+#endif
 }
 
 template <int TW, int WM, int WN, int CK, int SRC>
 static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
     constexpr int TC = TW / 2, TR = 32 / TC, TH = WM * 2 * TR;
-    constexpr size_t lds = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32) * (CK + 4) * sizeof(float);
+    constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32) * (CK + 4) * sizeof(float);
+    constexpr size_t lds_out = (size_t)TH * TW * (WN * 32 + 4) * sizeof(float);
+    constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
     auto kern = conv3x3_winograd_kernel<TW, WM, WN, CK, SRC>;
     static bool cap = false;
     if (!cap) {
