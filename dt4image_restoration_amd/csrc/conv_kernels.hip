@@ -270,6 +270,26 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         __syncthreads();
         constexpr int V4 = BN / 4;
         const int cbase = cbt * BN;
+        if constexpr (BN == 32 && BM == 256) {
+            if (a.last_w != nullptr) {
+                // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp; this conv's own
+                // 32-channel output is never written.  One pixel per thread.
+                const int gy = ty0 + tid / TW, gx = tx0 + tid % TW;
+                if (gy < a.H && gx < a.W) {
+                    float dsum = a.last_b[0];
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 v = *reinterpret_cast<const float4*>(&patch[tid * OSTR + 4 * c4]);
+                        const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * c4);
+                        dsum += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                    }
+                    const size_t q = ((size_t)n * a.H + gy) * a.W + gx;
+                    const float img = a.last_ximg != nullptr ? a.last_ximg[q] : (a.last_z[q].x - a.last_u[q].x);
+                    a.last_out[q] = fminf(fmaxf(img + dsum, 0.f), 1.f);
+                }
+                return;
+            }
+        }
 #pragma unroll 4
         for (int f = tid; f < BM * V4; f += 256) {
             const int p = f / V4, c4 = f % V4;
@@ -384,7 +404,7 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
 }
 
 // The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
-bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout) {
+bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout) {   // also: can fuse the last layer
     const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout);
     return p.splitk == 1 && p.mt == 2 && p.nt == 1 && p.wm == 4;
 }
@@ -395,64 +415,92 @@ size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// First conv: Cin = 2 (image, sigma plane), K = 18.  Direct f32 FMA; 8 lanes share a pixel, 4 couts each,
-// so a wave stores 8 pixels x 128 B contiguous.  The sigma plane is never materialised; like every
-// conv input it is ZERO in the padding halo (noise.py:161-162 cat, then conv with padding=1).
+// First conv: Cin = 2 (image, sigma plane), K = 18: too thin for MFMA, direct f32 FMA.  A workgroup owns an 8 x 32
+// pixel tile: the image channel d = ximg (or Re(z - u)) and the in-image mask of the halo are staged in LDS once;
+// 8 lanes share a pixel (4 output channels each, weights in registers), walk down the tile's 8 rows with a sliding
+// 3-row window (6 LDS reads per pixel instead of 18 global loads) and store 8 pixels x 128 B contiguous per wave.
+// The sigma plane is never materialised; like every conv input it is ZERO in the padding halo (noise.py:161-162 cat,
+// then conv with padding=1), which is what the mask plane encodes.
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ ximg, const float2* __restrict__ z,
                                                          const float2* __restrict__ u, const float* __restrict__ sigma,
                                                          const float* __restrict__ tact, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ dst,
-                                                         int N, int H, int W) {
-    const int cg = threadIdx.x & 7;
-    float wr[4][18];
-    float br[4];
+                                                         int N, int H, int W, int tilesX, int tilesY) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
+    __shared__ float dt[PH][PW + 1];
+    __shared__ float mt[PH][PW + 1];
+    int bt = blockIdx.x;
+    const int tx0 = (bt % tilesX) * TW;
+    bt /= tilesX;
+    const int ty0 = (bt % tilesY) * TH;
+    const int n = bt / tilesY;
+    if (tact != nullptr && tact[n] > 0.5f) return;
+    for (int i = threadIdx.x; i < PH * PW; i += 256) {
+        const int py = i / PW, px = i % PW;
+        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+        float d = 0.f, m = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t q = ((size_t)n * H + gy) * W + gx;
+            d = ximg != nullptr ? ximg[q] : (z[q].x - u[q].x);
+            m = 1.f;
+        }
+        dt[py][px] = d;
+        mt[py][px] = m;
+    }
+    const int cg = threadIdx.x & 7, col = threadIdx.x >> 3;
+    float wd[4][9], ws[4][9], br[4];
+    const float sg = sigma[n];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         br[j] = bias[cg * 4 + j];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) wr[j][k] = w[(cg * 4 + j) * 18 + k];
+        for (int k = 0; k < 9; ++k) {
+            wd[j][k] = w[(cg * 4 + j) * 18 + k];
+            ws[j][k] = w[(cg * 4 + j) * 18 + 9 + k] * sg;      // sigma folded into the second channel's taps
+        }
     }
-    const size_t total = (size_t)N * H * W;
-    for (size_t p = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); p < total; p += (size_t)gridDim.x * 32) {
-        const int gx = (int)(p % W);
-        const int gy = (int)((p / W) % H);
-        const int n = (int)(p / ((size_t)W * H));
-        if (tact != nullptr && tact[n] > 0.5f) continue;
-        const float sg = sigma[n];
+    __syncthreads();
+    float d[3][3], m[3][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d[r + 1][c] = dt[r][col + c]; m[r + 1][c] = mt[r][col + c]; }
+    const int gx = tx0 + col;
+#pragma unroll
+    for (int row = 0; row < TH; ++row) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                          // slide the window one row down
+            d[0][c] = d[1][c]; d[1][c] = d[2][c]; d[2][c] = dt[row + 2][col + c];
+            m[0][c] = m[1][c]; m[1][c] = m[2][c]; m[2][c] = mt[row + 2][col + c];
+        }
         float acc[4] = {br[0], br[1], br[2], br[3]};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int yy = gy + ky - 1, xx = gx + kx - 1;
-                float d = 0.f, sv = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                    const size_t q = ((size_t)n * H + yy) * W + xx;
-                    d = ximg != nullptr ? ximg[q] : (z[q].x - u[q].x);
-                    sv = sg;
-                }
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[j] = fmaf(wr[j][ky * 3 + kx], d, acc[j]);
-                    acc[j] = fmaf(wr[j][9 + ky * 3 + kx], sv, acc[j]);
+                    acc[j] = fmaf(wd[j][ky * 3 + kx], d[ky][kx], acc[j]);
+                    acc[j] = fmaf(ws[j][ky * 3 + kx], m[ky][kx], acc[j]);
                 }
-            }
-        float4 o;
-        o.x = acc[0] > 0.f ? acc[0] : kLeaky * acc[0];
-        o.y = acc[1] > 0.f ? acc[1] : kLeaky * acc[1];
-        o.z = acc[2] > 0.f ? acc[2] : kLeaky * acc[2];
-        o.w = acc[3] > 0.f ? acc[3] : kLeaky * acc[3];
-        *reinterpret_cast<float4*>(dst + p * 32 + cg * 4) = o;
+        const int gy = ty0 + row;
+        if (gy < H && gx < W) {
+            float4 o;
+            o.x = fmaxf(acc[0], kLeaky * acc[0]);
+            o.y = fmaxf(acc[1], kLeaky * acc[1]);
+            o.z = fmaxf(acc[2], kLeaky * acc[2]);
+            o.w = fmaxf(acc[3], kLeaky * acc[3]);
+            *reinterpret_cast<float4*>(dst + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o;
+        }
     }
 }
 
 hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
                              const float* tact, const float* w, const float* bias, float* dst, int N, int H, int W,
                              hipStream_t s) {
-    const size_t total = (size_t)N * H * W;
-    unsigned blocks = (unsigned)((total + 31) / 32);
-    if (blocks > 256u * 32u) blocks = 256u * 32u;
-    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, s, ximg, z, u, sigma, tact, w, bias, dst, N, H, W);
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tilesX * tilesY * N)), dim3(256), 0, s, ximg, z, u, sigma, tact, w,
+                       bias, dst, N, H, W, tilesX, tilesY);
     return hipGetLastError();
 }
 

@@ -60,6 +60,7 @@ struct pnp_engine {
     LevelBufs lv[5] = {};
     float* d_partial = nullptr;      // split-K workspace (small problems)
     bool wino[N_LAYERS] = {};         // layer runs on the Winograd kernel (weights packed for it)
+    bool fuse_last = false;           // last 1x1 layer rides in the epilogue of up4.conv-2
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
     // data-fidelity stage
     FftPlan plan = {};
@@ -155,14 +156,26 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
     }
     // up1..4: conv-0 reads cat([skip, bilinear_up(low)]) while staging
     const float* low = e->lv[4].s;
-    for (int k = 3; k >= 0; --k) {
+    for (int k = 3; k >= 1; --k) {
         const int b = 15 + 3 * (3 - k);
         if ((rc = conv(b, e->lv[k].s, low, e->lv[k].p, k))) return rc;
         if ((rc = conv(b + 1, e->lv[k].p, nullptr, e->lv[k].q, k))) return rc;
         if ((rc = conv(b + 2, e->lv[k].q, nullptr, e->lv[k].p, k))) return rc;
         low = e->lv[k].p;
     }
-    {
+    if ((rc = conv(24, e->lv[0].s, low, e->lv[0].p, 0))) return rc;
+    if ((rc = conv(25, e->lv[0].p, nullptr, e->lv[0].q, 0))) return rc;
+    if (e->fuse_last) {
+        // up4.conv-2 with the last layer (1x1 + residual + clamp) fused into its epilogue: writes `out` directly
+        const LayerSpec& L = kLayers[26];
+        ConvArgs a{};
+        a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
+        a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
+        a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
+        Prof p(e, s, 0, 26);
+        HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
+    } else {
+        if ((rc = conv(26, e->lv[0].q, nullptr, e->lv[0].p, 0))) return rc;
         Prof p(e, s, 2, 27);
         HIP_TRY(launch_conv_last(e->lv[0].p, ximg, z, u, tact, e->d_wpack[27], e->d_bias[27], out, N, H, W, s));
     }
@@ -311,6 +324,7 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
         e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout));
     }
+    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && !e->wino[26] && conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout);
     e->weights_loaded = true;
     return PNP_OK;
 }
@@ -386,6 +400,7 @@ int pnp_psnr(pnp_handle e, const float* x, const float* gt, float* out, void* st
 
 int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, int* ww, void* stream) {
     if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
+    if (which == 8 && e->fuse_last) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 8 is fused away; create the handle with PNP_FLAG_KEEP_STAGES");
     // stage outputs: inc, down1..4 live in lv[k].s; up1..4 in lv[3..0].p
     const int lvl = which <= 4 ? which : 8 - which;
     const LevelBufs& L = e->lv[lvl];

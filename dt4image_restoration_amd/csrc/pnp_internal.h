@@ -24,6 +24,8 @@ struct ConvArgs {
     const float* bias;   // [Cout]
     float* dst;          // [N,H,W,Cout]
     float* pooled;       // optional: also write MaxPool2d(2) of the output, [N,H/2,W/2,Cout] (H, W even)
+    // optional fused last layer (1x1 conv 32 -> 1 + image residual + clamp), Cout = 32 LDS-epilogue plan only:
+    const float* last_w; const float* last_b; const float* last_ximg; const float2* last_z; const float2* last_u; float* last_out;
     float* partial;      // split-K workspace, conv3x3_partial_floats() floats (small problems only)
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size

@@ -50,6 +50,8 @@ typedef struct {
 
 #define PNP_FLAG_PROFILE 1       /* record a HIP event pair around every kernel launch (pnp_profile_*) */
 #define PNP_FLAG_NO_DENOISER 2   /* k-space-only handle (pnp_fft2c / pnp_psnr): no activation planes */
+#define PNP_FLAG_KEEP_STAGES 4   /* keep every U-Net stage output in memory for pnp_unet_read_stage (disables the
+                                    fusion of the last 1x1 layer into the preceding conv's epilogue) */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 
@@ -116,7 +118,8 @@ int pnp_psnr(pnp_handle h, const float* x, const float* gt, float* out, void* st
 
 /* Copy one internal activation of the LAST denoiser forward to `dst` (DEVICE float32, NCHW
  * [N,C,h,w]) for per-stage parity tests.  which: 0..8 = stage outputs inc, down1..4, up1..4
- * (the tensors x1..x5, y1..y4 of evaluation/noise.py:120-128).  Returns C,h,w via out params. */
+ * (the tensors x1..x5, y1..y4 of evaluation/noise.py:120-128).  Returns C,h,w via out params.  Stage 8 (y4) is only
+ * materialised on handles created with PNP_FLAG_KEEP_STAGES. */
 int pnp_unet_read_stage(pnp_handle h, int which, float* dst, int* c, int* hh, int* ww, void* stream);
 
 /* Kernel-level timing (PNP_FLAG_PROFILE).  After the stream has been synchronised by the caller,

@@ -16,9 +16,9 @@ def sd_np():
     return weights.generate_unet_weights(0, "unit_gain")
 
 
-def _engine(n, h, w, sd=None, profile=False):
+def _engine(n, h, w, sd=None, profile=False, keep_stages=False):
     from dt4image_restoration_amd.engine import PnPEngine
-    e = PnPEngine(n, h, w, profile=profile)
+    e = PnPEngine(n, h, w, profile=profile, keep_stages=keep_stages)
     if sd is not None:
         e.load_weights(sd)
     return e
@@ -50,7 +50,7 @@ def test_fft2c_golden_and_roundtrip(golden_dir):
 
 @pytest.mark.parametrize("n,h,w", [(1, 32, 32), (2, 48, 64), (1, 128, 128), (3, 64, 16), (2, 16, 16)])
 def test_denoiser_matches_oracle_per_stage(sd_np, n, h, w):
-    e = _engine(n, h, w, sd_np)
+    e = _engine(n, h, w, sd_np, keep_stages=True)
     sd = O.torch_weights(sd_np)
     x = (torch.from_numpy(synthetic.hash_uniform(5, h * 100 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
     sigma = torch.linspace(5, 50, n) / 255.0
@@ -65,6 +65,13 @@ def test_denoiser_matches_oracle_per_stage(sd_np, n, h, w):
         assert err < 5e-5 * max(1.0, float(ref.abs().max())), f"stage {name}: max err {err}"
     ref = torch.clamp(ref_raw, 0, 1)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5)
+    # the production handle fuses the last 1x1 layer into the preceding conv: same output, stage 8 not materialised
+    from dt4image_restoration_amd._lib import PnPError
+    e2 = _engine(n, h, w, sd_np)
+    got2 = e2.denoise(x.cuda(), sigma.cuda())
+    np.testing.assert_allclose(got2.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5)
+    with pytest.raises(PnPError):
+        e2.read_stage(8)
 
 
 def test_denoiser_golden_from_reference(sd_np, golden_dir):
