@@ -412,6 +412,13 @@ int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, in
     return PNP_OK;
 }
 
+int pnp_conv_algorithms(pnp_handle e, int32_t* algo28) {
+    if (!e || !algo28) return fail(PNP_ERR_INVALID, "pnp_conv_algorithms: null argument");
+    if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_conv_algorithms: weights not loaded");
+    for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? 1 : 0));
+    return PNP_OK;
+}
+
 int pnp_profile_reset(pnp_handle e) {
     if (!e) return fail(PNP_ERR_INVALID, "null handle");
     e->ev_used = 0;

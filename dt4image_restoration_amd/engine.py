@@ -150,6 +150,12 @@ class PnPEngine:
                    "pnp_unet_read_stage")
         return out
 
+    def conv_algorithms(self):
+        """Per conv layer: 0 direct MFMA, 1 Winograd MFMA, 2 first layer (VALU), 3 last layer."""
+        out = (C.c_int32 * _lib.N_LAYERS)()
+        _lib.check(self.lib.pnp_conv_algorithms(self._h, out), "pnp_conv_algorithms")
+        return list(out)
+
     # -- kernel timing ---------------------------------------------------------------------
     def profile_reset(self) -> None:
         _lib.check(self.lib.pnp_profile_reset(self._h), "pnp_profile_reset")
