@@ -38,6 +38,16 @@ def mfma_conv_flops(n, h, w):
                    for l in unet_spec.UNET_LAYERS[1:27])
 
 
+def conv_traffic_bytes(n, h, w):
+    """PMC-measured HBM traffic of the conv kernels per step (profiles/r01_traffic.json, configs[1] only)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if (n, h, w) != (64, 256, 256) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return int(t["conv_kernels_fetch_bytes_per_step"] + t["conv_kernels_write_bytes_per_step"])
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask and cgroup quota, not the machine's core count
     (a 1-GPU box exposes 256 logical CPUs but grants a 16-core share)."""
@@ -177,7 +187,9 @@ def main():
                           f"with Cin>=32; {sum(1 for v in algos if v == 1)} on Winograd F(2x2,3x3), {sum(1 for v in algos if v == 0)} direct)",
                 "bound": "mfma", "achieved": round(achieved, 3) if achieved else None, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                "traffic": None,
+                "traffic": conv_traffic_bytes(n, h, w),
+                "traffic_note": "HBM bytes per step of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 "
+                                "correction + WRITE_SIZE, separate passes; profiles/r01_traffic.json), not measured in this run",
                 "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / kernel time; Winograd layers issue 16/36 of "
                         "those multiplies, so frac can exceed 1.  executed = MFMA FLOPs actually issued / kernel time.",
                 "executed": round(executed, 3) if executed else None,
