@@ -77,10 +77,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     constexpr int PWL = TW + 2, PH = TH + 2, PW = PWL;
     constexpr int ITEMS = PH * PWL * PPP;
     constexpr int NIT = (ITEMS + 255) / 256;
-    // PLAIN: raw loads of the next chunk are held in registers across the MFMA phase.  UPCAT (4 float4 per piece) does
-    // not fit: prefetching all pieces, or even staging them in one synchronous batch, spills and measured 5-15 % slower
-    // than three batches of 3 pieces.
-    constexpr bool PREFETCH = SRC == SRC_PLAIN;
+    // PLAIN chunks: the raw loads of the next chunk are held in registers across the MFMA phase.  UPCAT chunks that come
+    // from the bilinear x2 upsample (4 source pixels per patch pixel) do not fit in registers that way (spills, 5-15 %
+    // slower) and staged synchronously they cost 30 % of the kernel.  Instead the LOW-RES source region of the tile,
+    // (TH/2+3) x (TW/2+3) pixels - 13x fewer loads - is prefetched like a PLAIN chunk, parked in LDS, and the patch is
+    // interpolated LDS -> LDS.  POOL sources (only used when no pooled copy exists) stage synchronously in batches.
+    constexpr bool UP2 = SRC == SRC_UPCAT;
+    constexpr bool PREFETCH = SRC == SRC_PLAIN || UP2;
+    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;        // low-res region bound (rows, cols)
+    constexpr int LITEMS = LH * LW * PPP;
+    constexpr int NITL = (LITEMS + 255) / 256;
+    constexpr int NRAW = PREFETCH ? (UP2 && NITL > NIT ? NITL : NIT) : (NIT < 3 ? NIT : 3);
     constexpr int LB = PREFETCH ? NIT : (NIT < 3 ? NIT : 3);
     constexpr int KSC = CK / 8;                // k-steps per chunk
     constexpr int PAIRS = 16 * KSC;            // (k-step, frequency) pairs per chunk, 4 MFMAs each
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKP]
     float* const V = smem + PH * PW * CKP;                 // [16][NTILES][CKP]
+    float* const lowres = V + 16 * NTILES * CKP;           // UPCAT: [LH][LW][CKP] low-res source region
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -104,19 +112,79 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     if (a.tact != nullptr && a.tact[n] > 0.5f) return;
     const int nchunks = a.Cin / CK;
 
-    RawPiece<SRC> raw[PREFETCH ? NIT : LB];
+    // UPCAT geometry of this tile: low-res rows/cols [ylo, ylo+LH) x [xlo, xlo+LW) cover every source pixel of the patch
+    const int Hs = a.H >> 1, Ws = a.W >> 1;
+    const int ylo = UP2 ? (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)) : 0;
+    const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
+    const int nskip = UP2 ? a.Cskip / CK : 0;              // leading chunks that come straight from the skip tensor
+
+    float4 raw[NRAW][(SRC == SRC_POOL) ? 4 : 1];
     auto issue = [&](int c, int it0, int cnt) {
+        if (UP2 && c >= nskip) {                           // low-res region of an upsampled chunk
+            const int Cup = a.Cin - a.Cskip;
+            const float* base = a.src1 + (size_t)n * Hs * Ws * Cup + (c * CK - a.Cskip);
+#pragma unroll
+            for (int k = 0; k < NITL; ++k) {
+                const int idx = tid + k * 256;
+                const int part = idx % PPP, pp = idx / PPP;
+                const int sy = ylo + pp / LW, sx = xlo + pp % LW;
+                if (idx < LITEMS && sy < Hs && sx < Ws)
+                    raw[k][0] = *reinterpret_cast<const float4*>(base + ((size_t)sy * Ws + sx) * Cup + part * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
             const int idx = tid + (it0 + k) * 256;
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PWL, px = pp % PWL;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                issue_piece<SRC>(a, n, gy, gx, c * CK + part * 4, raw[k]);
+            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                if constexpr (SRC == SRC_POOL) {
+                    RawPiece<SRC_POOL> r;
+                    issue_piece<SRC_POOL>(a, n, gy, gx, c * CK + part * 4, r);
+                    raw[k][0] = r.v[0]; raw[k][1] = r.v[1]; raw[k][2] = r.v[2]; raw[k][3] = r.v[3];
+                } else {                                   // PLAIN, or a skip chunk of UPCAT
+                    const int cs = UP2 ? a.Cskip : a.Cin;
+                    raw[k][0] = *reinterpret_cast<const float4*>(a.src0 + (((size_t)n * a.H + gy) * a.W + gx) * cs + c * CK + part * 4);
+                }
+            }
         }
     };
     auto commit = [&](int c, int it0, int cnt) {
+        if (UP2 && c >= nskip) {
+            // park the low-res region in LDS, then interpolate the patch from it (ATen upsample_bilinear2d,
+            // align_corners=True: src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
+#pragma unroll
+            for (int k = 0; k < NITL; ++k) {
+                const int idx = tid + k * 256;
+                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKP + (idx % PPP) * 4]) = raw[k][0];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int part = idx % PPP, pp = idx / PPP;
+                const int py = pp / PWL, px = pp % PWL;
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                if (idx < ITEMS) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                        const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
+                        const int y0 = (int)sy, x0 = (int)sx;
+                        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                        const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+                        const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * CKP + part * 4];
+                        const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * CKP + part * 4];
+                        v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * CKP), *reinterpret_cast<const float4*>(r0 + x1 * CKP),
+                                    *reinterpret_cast<const float4*>(r1 + x0 * CKP), *reinterpret_cast<const float4*>(r1 + x1 * CKP),
+                                    1.f - lx, lx, 1.f - ly, ly);
+                    }
+                    *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
             const int idx = tid + (it0 + k) * 256;
@@ -124,8 +192,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
             const int py = pp / PWL, px = pp % PWL;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             if (idx < ITEMS) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    if constexpr (SRC == SRC_POOL) v = f4max(f4max(raw[k][0], raw[k][1]), f4max(raw[k][2], raw[k][3]));
+                    else v = raw[k][0];
+                }
                 *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
             }
         }
@@ -290,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
 template <int TW, int WM, int WN, int CK, int SRC>
 static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
     constexpr int TC = TW / 2, TR = 32 / TC, TH = WM * 2 * TR;
-    constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32) * (CK + 4) * sizeof(float);
+    constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * (CK + 4) * sizeof(float);
     constexpr size_t lds_out = (size_t)TH * TW * (WN * 32 + 4) * sizeof(float);
     constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
     auto kern = conv3x3_winograd_kernel<TW, WM, WN, CK, SRC>;
