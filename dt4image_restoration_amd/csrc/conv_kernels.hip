@@ -132,11 +132,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     const int tx0 = (bt % a.tilesX) * TW;
     bt /= a.tilesX;
     const int ty0 = (bt % a.tilesY) * TH;
-#ifdef PNP_EXP_SAMEIMG
-    const int n = 0; (void)bt;
-#else
     const int n = bt / a.tilesY;
-#endif
     const int cbt = blockIdx.y;
     if (a.tact != nullptr && a.tact[n] > 0.5f) return;   // slice is done: leave its planes untouched
 

@@ -221,27 +221,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
     const int aoff = (wm * 32 + li) * CKP + 4 * hh;        // this lane's row of V[xi]
 
-#ifdef PNP_DIAG
-    long long dg[6] = {0, 0, 0, 0, 0, 0};
-    long long dt = __builtin_amdgcn_s_memtime();
-#define DG(i) { const long long t_ = __builtin_amdgcn_s_memtime(); dg[i] += t_ - dt; dt = t_; }
-#else
-#define DG(i)
-#endif
     for (int c = 0; c < nchunks; ++c) {
         if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
-        DG(0)
         if (PREFETCH) {
             commit(c, 0, NIT);
         } else {
 #pragma unroll 1
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
-        DG(1)
         __syncthreads();
-        DG(0)
         if (PREFETCH && c + 1 < nchunks) issue(c + 1, 0, NIT);
-        DG(2)
 
         // ---- input transform V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] ------------------------
         {
@@ -269,9 +258,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
                 *reinterpret_cast<float4*>(&V[(4 * i + 3) * NTILES * CKP + vout]) = v3;
             }
         }
-        DG(3)
         __syncthreads();
-        DG(0)
 
         // ---- 16 GEMMs: pair p = (k-step, xi); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair ----
         const float4* bp = bptr + (size_t)c * PAIRS * 64;
@@ -293,7 +280,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
             bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
             if (p + 1 < PAIRS) a0 = a1;
         }
-        DG(4)
     }
     {
     // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]) + LeakyReLU, lane-local; the results go through
@@ -351,11 +337,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
         }
     }
     }
-#ifdef PNP_DIAG
-    DG(5)
-    if (blockIdx.x == 3 && blockIdx.y == 0 && tid == 0)
-        printf("WINO Cin %d Cout %d chunks %d: barrier %lld commit %lld issue %lld transform %lld mfma %lld epilogue %lld\n", a.Cin, a.Cout, nchunks, dg[0], dg[1], dg[2], dg[3], dg[4], dg[5]);
-#endif
 }
 
 template <int TW, int WM, int WN, int CK, int SRC>
