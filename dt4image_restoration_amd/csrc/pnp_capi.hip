@@ -173,7 +173,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
         Prof p(e, s, 0, 26);
-        HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
+        if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, SRC_PLAIN, s));
+        else HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
     } else {
         if ((rc = conv(26, e->lv[0].q, nullptr, e->lv[0].p, 0))) return rc;
         Prof p(e, s, 2, 27);
@@ -324,7 +325,7 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
         e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout));
     }
-    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && !e->wino[26] && conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout);
+    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout));
     e->weights_loaded = true;
     return PNP_OK;
 }

@@ -16,6 +16,7 @@
 // LeakyReLU and the NHWC stores are lane-local.  256 accumulator registers per lane => one wave per SIMD.
 #include "pnp_internal.h"
 #include "conv_staging.h"
+#include <cstdlib>
 
 namespace pnp {
 
@@ -49,14 +50,18 @@ void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* 
     for (int i = 0; i < 4 * 256; ++i) dst[o++] = 0.f;
 }
 
-// Eligibility + tile plan.  The transforms and the 16-accumulator epilogue are per-item overhead that only long K
-// amortises; short-K layers (Cin < 64) and small problems stay on the direct kernel.
+// Eligibility + tile plan.  The transforms and the 16-accumulator epilogue are per-item overhead that long K amortises
+// best (1.65x over the direct kernel at Cin >= 128), but even the K = 288 layers gain ~9 %; small problems (too few
+// workgroups) stay on the direct kernel with split-K.
 WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
     WinoPlan p{};
     p.use = false;
-    if (Cin < 64 || Cout < 64 || Cin % 32 || Cout % 64) return p;
+    const int min_cin = getenv("PNP_WINO_MIN_CIN") ? atoi(getenv("PNP_WINO_MIN_CIN")) : 32;   // experiments: raise to compare
+    if (Cin < min_cin || Cin % 32 || Cout % 32) return p;
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
-    if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; p.ck = 32; } else { p.wm = 2; p.wn = 2; p.ck = 16; }
+    if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; p.ck = 32; }
+    else if (Cout % 64 == 0) { p.wm = 2; p.wn = 2; p.ck = 16; }
+    else { p.wm = 4; p.wn = 1; p.ck = 8; }                  // Cout = 32: 128 tiles x 32 channels per workgroup
     const int tc = p.tw / 2, tr = 32 / tc;
     p.th = p.wm * 2 * tr;
     p.bn = p.wn * 32;
@@ -314,6 +319,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const ConvArgs
     __syncthreads();
     constexpr int V4 = BN / 4;                             // float4 per pixel
     const int cbase = blockIdx.y * BN;
+    if constexpr (BN == 32) {
+        if (a.last_w != nullptr) {
+            // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp; this conv's own
+            // 32-channel output is never written.
+            for (int p = tid; p < TH * TW; p += 256) {
+                const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+                if (gy < a.H && gx < a.W) {
+                    float dsum = a.last_b[0];
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 v = *reinterpret_cast<const float4*>(&otile[p * OSTR + 4 * c4]);
+                        const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * c4);
+                        dsum += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                    }
+                    const size_t q = ((size_t)n * a.H + gy) * a.W + gx;
+                    const float img = a.last_ximg != nullptr ? a.last_ximg[q] : (a.last_z[q].x - a.last_u[q].x);
+                    a.last_out[q] = fminf(fmaxf(img + dsum, 0.f), 1.f);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll 4
     for (int f = tid; f < TH * TW * V4; f += 256) {
         const int p = f / V4, c4 = f % V4;
@@ -370,7 +397,8 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, const WinoPlan& p, int src_
 template <int TW>
 static hipError_t launch_wino_tw(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s) {
     if (p.wm == 1) return launch_wino_cfg<TW, 1, 4, 32>(a, p, src_mode, s);
-    return launch_wino_cfg<TW, 2, 2, 16>(a, p, src_mode, s);
+    if (p.wm == 2) return launch_wino_cfg<TW, 2, 2, 16>(a, p, src_mode, s);
+    return launch_wino_cfg<TW, 4, 1, 8>(a, p, src_mode, s);
 }
 
 // `a.wpack` must be the Winograd pack (pack_winograd_weights with the plan's ck).
