@@ -62,9 +62,14 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
     const int min_cin = getenv("PNP_WINO_MIN_CIN") ? atoi(getenv("PNP_WINO_MIN_CIN")) : 32;   // experiments: raise to compare
     if (Cin < min_cin || Cin % 32 || Cout % 32) return p;
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
-    if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; p.ck = 32; }
-    else if (Cout % 64 == 0) { p.wm = 2; p.wn = 2; p.ck = 16; }
-    else { p.wm = 4; p.wn = 1; p.ck = 8; }                  // Cout = 32: 128 tiles x 32 channels per workgroup
+    // Cout >= 128: one 8-wave workgroup per CU (32 tiles x 128 channels, 32-channel chunks).  Cout = 64 / 32: 4-wave
+    // workgroups (32 tiles x 64 channels / 64 tiles x 32 channels) small enough for TWO per CU, so one workgroup's
+    // barriers, transforms, prologue loads and epilogue run under the other's MFMAs - their chunks are short (64 / 32
+    // MFMAs per wave), which made per-chunk overhead the bound with a single resident workgroup.
+    const bool big = getenv("PNP_WINO_BIG_GROUPS") != nullptr;          // experiments: the 8-wave plans everywhere
+    if (Cout % 128 == 0 && getenv("PNP_WINO_SMALL_GROUPS") == nullptr) { p.wm = 1; p.wn = 4; p.ck = 32; }
+    else if (Cout % 64 == 0) { if (big) { p.wm = 2; p.wn = 2; } else { p.wm = 1; p.wn = 2; } p.ck = 16; }
+    else { if (big) { p.wm = 4; p.wn = 1; } else { p.wm = 2; p.wn = 1; } p.ck = 8; }
     const int tc = p.tw / 2, tr = 32 / tc;
     p.th = p.wm * 2 * tr;
     p.bn = p.wn * 32;
@@ -77,8 +82,9 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
 }
 
 template <int TW, int WM, int WN, int CK, int SRC>
-__global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs a) {
-    constexpr int NT_ = 512;                   // threads: 8 waves = 2 frequency halves x WM tile groups x WN channel groups
+__global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(const ConvArgs a) {
+    constexpr int GW = WM * WN;                // (tile group, channel group) pairs; each is served by TWO waves
+    constexpr int NT_ = GW * 128;              // threads: 2 frequency halves x WM tile groups x WN channel groups waves
     constexpr int CKP = CK + 4;
     constexpr int PPP = CK / 4;
     constexpr int TC = TW / 2, TR = 32 / TC;   // tiles per row / rows of tiles in one 32-tile M-block
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs
     constexpr int KSC = CK / 8;                // k-steps per chunk
     constexpr int PAIRS = 8 * KSC;             // (k-step, frequency) pairs per chunk and wave, 4 MFMAs each
     constexpr int PF = 4;                      // B fragments in flight
-    static_assert(WM * WN == 4 && NTILES * PPP == 256, "one (tile, 4-channel, frequency-half) transform item per thread");
+    static_assert((GW == 4 || GW == 2) && NTILES * PPP * 2 == NT_, "one (tile, 4-channel, frequency-half) transform item per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKP]
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs
     float* const lowres = V + 16 * NTILES * CKP;           // UPCAT: [LH][LW][CKP] low-res source region
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int xh = wid >> 2;                               // frequency half: V rows {2xh, 2xh+1}, xi = 8*xh + k
-    const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
+    const int xh = wid / GW;                               // frequency half: V rows {2xh, 2xh+1}, xi = 8*xh + k
+    const int wm = (wid % GW) / WN, wn = (wid % GW) % WN;
     const int hh = lane >> 5, li = lane & 31;
 
     int bt = blockIdx.x;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs
 
     // this thread's transform item: tile tq of the workgroup's tile grid (TC wide), channels [4*tg, 4*tg+4), and the
     // two V rows of frequency half xh (the half this thread's own wave consumes)
-    const int t8 = tid & 255;
+    const int t8 = tid % (NT_ / 2);
     const int tg = t8 % PPP, tq = t8 / PPP;
     const int win = ((2 * (tq / TC)) * PW + 2 * (tq % TC)) * CKP + 4 * tg;     // top-left of the 4x4 input window
     const int vout = tq * CKP + 4 * tg;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs
     constexpr int BN = WN * 32;
     constexpr int OSTR = BN + 4;                           // floats per pixel row of the LDS output tile
     float* const otile = smem;                             // [TH*TW][OSTR]
-    float* const exch = smem;                              // [8 waves][16 r][2 b][64 lanes]
+    float* const exch = smem;                              // [2*GW waves][16 r][2 b][64 lanes]
     float ta0[16], ta1[16], tb0[16], tb1[16];              // T of this half's first / second row, b = 0 / 1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -331,8 +337,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd_kernel(const ConvArgs
     float y0[16], y1[16];                                  // this half's output row, columns b = 0 / 1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float g0 = exch[(((wid ^ 4) * 16 + r) * 2 + 0) * 64 + lane];
-        const float g1 = exch[(((wid ^ 4) * 16 + r) * 2 + 1) * 64 + lane];
+        const float g0 = exch[(((wid ^ GW) * 16 + r) * 2 + 0) * 64 + lane];
+        const float g1 = exch[(((wid ^ GW) * 16 + r) * 2 + 1) * 64 + lane];
         if (xh == 0) { y0[r] = ta0[r] + tb0[r] + g0; y1[r] = ta1[r] + tb1[r] + g1; }      // T_0 + T_1 + T_2
         else         { y0[r] = g0 - ta0[r] - tb0[r]; y1[r] = g1 - ta1[r] - tb1[r]; }      // T_1 - T_2 - T_3
     }
@@ -398,7 +404,7 @@ static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStre
     constexpr int TC = TW / 2, TR = 32 / TC, TH = WM * 2 * TR;
     constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 16 * WM * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * (CK + 4) * sizeof(float);
     constexpr size_t lds_out = (size_t)TH * TW * (WN * 32 + 4) * sizeof(float);
-    constexpr size_t lds_x = 8 * 16 * 2 * 64 * sizeof(float);      // cross-wave exchange of the output transform
+    constexpr size_t lds_x = (size_t)(2 * WM * WN) * 16 * 2 * 64 * sizeof(float);   // cross-wave exchange of the output transform
     constexpr size_t lds = (lds_main > lds_out ? lds_main : lds_out) > lds_x ? (lds_main > lds_out ? lds_main : lds_out) : lds_x;
     auto kern = conv3x3_winograd_kernel<TW, WM, WN, CK, SRC>;
     static bool cap = false;
@@ -408,7 +414,7 @@ static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStre
         cap = true;
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 128), lds, s, a);
     return hipGetLastError();
 }
 
@@ -424,8 +430,10 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, const WinoPlan& p, int src_
 
 template <int TW>
 static hipError_t launch_wino_tw(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s) {
-    if (p.wm == 1) return launch_wino_cfg<TW, 1, 4, 32>(a, p, src_mode, s);
-    if (p.wm == 2) return launch_wino_cfg<TW, 2, 2, 16>(a, p, src_mode, s);
+    if (p.wm == 1 && p.wn == 4) return launch_wino_cfg<TW, 1, 4, 32>(a, p, src_mode, s);
+    if (p.wm == 1 && p.wn == 2) return launch_wino_cfg<TW, 1, 2, 16>(a, p, src_mode, s);
+    if (p.wm == 2 && p.wn == 2) return launch_wino_cfg<TW, 2, 2, 16>(a, p, src_mode, s);
+    if (p.wm == 2 && p.wn == 1) return launch_wino_cfg<TW, 2, 1, 8>(a, p, src_mode, s);
     return launch_wino_cfg<TW, 4, 1, 8>(a, p, src_mode, s);
 }
 
