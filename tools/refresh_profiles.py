@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Fold the files a GPU run left under gpurun_out/ into profiles/ (round-1 names) and print the headline numbers.
+Usage: python tools/refresh_profiles.py <suffix of bench/prof dirs, e.g. r01f> <suffix of pmc dirs, e.g. 4>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag, pmc = sys.argv[1], sys.argv[2]
+
+shutil.copy(glob.glob(f"{G}/prof_{tag}/runc/*_kernel_stats.csv")[0], f"{P}/r01_kernel_stats.csv")
+shutil.copy(f"{G}/layers_{tag}.json", f"{P}/r01_layers.json")
+shutil.copy(f"{G}/bench_prof_{tag}.json", f"{P}/r01_bench_under_rocprof.json")
+shutil.copy(f"{G}/bench_{tag}.json", f"{P}/r01_bench.json")
+
+
+def load(d):
+    return list(csv.DictReader(open(glob.glob(f"{G}/{d}/runc/*_counter_collection.csv")[0])))
+
+
+out = {}
+for d, name in ((f"pmcF{pmc}", "FETCH_SIZE"), (f"pmcW{pmc}", "WRITE_SIZE")):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in load(d):
+        if r["Counter_Name"] == name:
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    out[name] = {k: (agg[k] / cnt[k], cnt[k]) for k in agg}
+tf = tw = 0
+rows = []
+for k, (v, c) in out["FETCH_SIZE"].items():
+    if "conv3x3" not in k:
+        continue
+    w = out["WRITE_SIZE"].get(k, (0, 0))[0]
+    tf += 2 * v * 1024 * c / 3
+    tw += w * 1024 * c / 3
+    rows.append((k[5:], c / 3, round(2 * v * 1024 / 1e6, 1), round(w * 1024 / 1e6, 1)))
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1; FETCH_SIZE x2 "
+                     "(gfx950), both x1024 (KB units)", "conv_kernels_fetch_bytes_per_step": tf,
+           "conv_kernels_write_bytes_per_step": tw, "per_kernel_launches_per_step_fetchMB_writeMB": rows},
+          open(f"{P}/r01_traffic.json", "w"), indent=1)
+
+rows = load(f"pmcS{pmc}")
+kt = {}
+for r in csv.DictReader(open(glob.glob(f"{G}/pmcS{pmc}/runc/*_kernel_trace.csv")[0])):
+    kt[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"])
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for r in rows:
+    agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+for d, (dur, name) in kt.items():
+    agg[name.split("(")[0]]["dur_ns"] += dur
+    cnt[name.split("(")[0]] += 1
+lines = ["| kernel | launches | avg us | clock GHz | MFMA busy / peak issue | WAIT_ANY | WAIT_INST_ANY | LDS bank conflict / SQ busy |",
+         "|---|---|---|---|---|---|---|---|"]
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["dur_ns"]):
+    if "conv3x3" not in k:
+        continue
+    n = cnt[k]
+    dur = v["dur_ns"] / n
+    gui = v["GRBM_GUI_ACTIVE"] / n
+    lines.append("| %s | %d | %.0f | %.2f | %.3f | %.2f | %.2f | %.3f |" % (
+        k[5:], n, dur / 1e3, gui / 8 / dur, v["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (gui / 8 * 256 * 4),
+        v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+        v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_BUSY_CYCLES"], 1)))
+open(f"{P}/r01_pmc_current.md", "w").write(
+    "# SQ counters of the conv kernels, current build (own rocprofv3 --pmc pass, bench.py --steps 2 --warmup 1)\n\n"
+    + "\n".join(lines) + f"\n\nHBM traffic of the conv kernels per step: {tf / 1e9:.2f} GB fetched (FETCH_SIZE x2) + {tw / 1e9:.2f} GB written.\n")
+d = json.load(open(f"{P}/r01_bench.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["executed"], "traffic GB", tf / 1e9, tw / 1e9)
+print("\n".join(lines))
