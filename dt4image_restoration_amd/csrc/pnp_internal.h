@@ -32,6 +32,9 @@ struct ConvArgs {
     int Cin, Cskip, Cout;
     int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
+#ifdef PNP_STAMPS
+    int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
+#endif
 };
 
 // Launch the conv3x3 (+bias +LeakyReLU 0.2) implicit-GEMM kernel matching `a` (picks the tile shape

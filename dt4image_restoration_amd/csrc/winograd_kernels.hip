@@ -6,19 +6,33 @@
 // (cin, cout) pair instead of 36, i.e. 2.25x fewer MFMAs, in exact f32 MFMA arithmetic (coefficients 1, 1/2, 1/4).
 // The f32 matrix pipe is the bound of the direct kernel (124 TF/s = 79 % of peak), so fewer MFMAs is the lever left.
 //
-// Workgroup = 4 waves = WM groups of 32 tiles x WN groups of 32 output channels.  Per CK-channel chunk:
-//   1. stage the (TH+2) x (TW+2) halo patch in LDS (same code path and input transforms as the direct kernel)
-//   2. input transform: thread (tile, 4 channels) reads its 4x4 window from the patch, V = B^T d B, writes the 16
-//      frequency planes V[xi][tile][channel] to LDS
-//   3. 16 independent GEMMs: for every frequency xi, acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment,
-//      transformed weights streamed from L2 in pre-packed per-lane order, 4 pairs ahead)
-// All 16 accumulators of a (tile, channel) element live in one lane, so the output transform Y = A^T M A, bias,
-// LeakyReLU and the NHWC stores are lane-local.  256 accumulator registers per lane => one wave per SIMD.
+// Workgroup = 2 frequency halves x WM groups of 32 tiles x WN groups of 32 output channels (4 or 8 waves; two waves
+// per SIMD, either of one 8-wave workgroup or of two resident 4-wave workgroups).  Per CK-channel chunk:
+//   1. stage the (TH+2) x (TW+2) halo patch in LDS (the loads of chunk c+1 are in flight during chunk c's MFMAs)
+//   2. input transform: thread (tile, 4 channels, frequency half) reads its 4x4 window from the patch and writes the
+//      8 frequency planes V[xi][tile][channel] its own wave pair consumes
+//   3. 16 independent GEMMs, 8 per wave: acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment, transformed
+//      weights streamed from L2 in pre-packed per-lane order, 4 pairs ahead)
+// The output transform Y = A^T M A is lane-local along columns and exchanges 2 floats per element with the partner wave
+// (other frequency half) through LDS along rows; bias, LeakyReLU, the pooled copy and the NHWC stores follow from LDS.
 #include "pnp_internal.h"
 #include "conv_staging.h"
 #include <cstdlib>
 
 namespace pnp {
+
+// Diagnostic build only (make STAMPS=1 -> libpnpadmm_stamps.so, read by tools/wino_stamps.py): wave 0 of 1024 mid-grid
+// workgroups per launch records s_memtime at its phase boundaries.
+#ifdef PNP_STAMPS
+#define PNP_STAMP_SLOTS 32
+#define PNP_STAMP_WGS 1024
+#define PNP_STAMP_N 112
+__device__ unsigned long long g_wino_stamps[PNP_STAMP_SLOTS * PNP_STAMP_WGS * PNP_STAMP_N];
+static int g_stamp_slot = 0;
+#define STAMP() do { if (ns < PNP_STAMP_N) st[ns] = __builtin_amdgcn_s_memtime(); ++ns; } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
 
 // ---- host: U = G g G^T, packed [cout/32][xi half][chunk][ks][k 8][lane][4]: one contiguous B stream per wave ---------
 size_t winograd_pack_floats(int cin, int cout) { return (size_t)(cout / 32) * ((size_t)(cin / 8) * 16 * 256 + 2 * 4 * 256); }
@@ -110,6 +124,11 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
     constexpr int PF = 4;                      // B fragments in flight
     static_assert((GW == 4 || GW == 2) && NTILES * PPP * 2 == NT_, "one (tile, 4-channel, frequency-half) transform item per thread");
 
+#ifdef PNP_STAMPS
+    unsigned long long st[PNP_STAMP_N];
+    int ns = 0;
+    STAMP();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKP]
     float* const V = smem + PH * PW * CKP;                 // [16][NTILES][CKP]
@@ -219,6 +238,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
         }
     };
     if (PREFETCH) issue(0, 0, NIT);
+    STAMP();                                               // [1] first loads issued
 
     // this thread's transform item: tile tq of the workgroup's tile grid (TC wide), channels [4*tg, 4*tg+4), and the
     // two V rows of frequency half xh (the half this thread's own wave consumes)
@@ -244,6 +264,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
     const int aoff = (8 * xh * NTILES + wm * 32 + li) * CKP + 4 * hh;              // this lane's row of V[8*xh]
 
     for (int c = 0; c < nchunks; ++c) {
+        STAMP();                                           // [2+4c] chunk top
         if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
         if (PREFETCH) {
             commit(c, 0, NIT);
@@ -252,6 +273,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
         __syncthreads();
+        STAMP();                                           // [3+4c] patch committed
         if (PREFETCH && c + 1 < nchunks) issue(c + 1, 0, NIT);
 
         // ---- input transform V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows 2xh, 2xh+1 -----------
@@ -286,6 +308,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
             }
         }
         __syncthreads();
+        STAMP();                                           // [4+4c] transformed
 
         // ---- 8 GEMMs per wave: pair p = (k-step, k); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair
         const float4* bp = bptr + (size_t)c * PAIRS * 64;
@@ -307,6 +330,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
             bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
             if (p + 1 < PAIRS) a0 = a1;
         }
+        STAMP();                                           // [5+4c] MFMA phase issued
     }
 
     // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  Column direction lane-local:
@@ -328,12 +352,14 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
         tb1[r] = acc[5][r] - acc[6][r] - acc[7][r];
     }
     __syncthreads();                                       // every wave has left its last MFMA phase: V is free
+    STAMP();                                               // [E0] MFMAs drained, column transform done
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                         // gift: half 0 sends T_1 (its second row), half 1 sends T_2 (its first)
         exch[((wid * 16 + r) * 2 + 0) * 64 + lane] = xh == 0 ? tb0[r] : ta0[r];
         exch[((wid * 16 + r) * 2 + 1) * 64 + lane] = xh == 0 ? tb1[r] : ta1[r];
     }
     __syncthreads();
+    STAMP();                                               // [Ea] gifts written
     float y0[16], y1[16];                                  // this half's output row, columns b = 0 / 1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -343,6 +369,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
         else         { y0[r] = g0 - ta0[r] - tb0[r]; y1[r] = g1 - ta1[r] - tb1[r]; }      // T_1 - T_2 - T_3
     }
     __syncthreads();                                       // the gifts have been read: the space becomes the output tile
+    STAMP();                                               // [Eb] gifts read
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;     // tile within the M-block (hh is per lane)
@@ -351,8 +378,10 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
         otile[(py * TW + px + 1) * OSTR + wn * 32 + li] = fmaxf(y1[r], kLeaky * y1[r]);
     }
     __syncthreads();
+    STAMP();                                               // [E1] output tile in LDS
     constexpr int V4 = BN / 4;                             // float4 per pixel
     const int cbase = blockIdx.y * BN;
+    bool fused_last = false;
     if constexpr (BN == 32) {
         if (a.last_w != nullptr) {
             // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp; this conv's own
@@ -372,9 +401,10 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
                     a.last_out[q] = fminf(fmaxf(img + dsum, 0.f), 1.f);
                 }
             }
-            return;
+            fused_last = true;
         }
     }
+    if (!fused_last) {
 #pragma unroll 4
     for (int f = tid; f < TH * TW * V4; f += NT_) {
         const int p = f / V4, c4 = f % V4;
@@ -397,6 +427,20 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
             }
         }
     }
+    }
+#ifdef PNP_STAMPS
+    STAMP();                                               // [E2] stores issued
+    {
+        const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
+        if (tid == 0 && blockIdx.y == 0 && w >= 0 && w < PNP_STAMP_WGS && a.stamp_slot < PNP_STAMP_SLOTS) {
+            unsigned long long* o = g_wino_stamps + ((size_t)a.stamp_slot * PNP_STAMP_WGS + w) * PNP_STAMP_N;
+            for (int i = 0; i < PNP_STAMP_N; ++i) o[i] = i < ns ? st[i] : 0ull;
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[PNP_STAMP_N - 1] = ((unsigned long long)ns << 32) | hwid;
+        }
+    }
+#endif
 }
 
 template <int TW, int WM, int WN, int CK, int SRC>
@@ -444,9 +488,20 @@ hipError_t launch_conv3x3_winograd(const ConvArgs& a0, int src_mode, hipStream_t
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
+#ifdef PNP_STAMPS
+    a.stamp_slot = g_stamp_slot++;
+#endif
     if (p.tw == 32) return launch_wino_tw<32>(a, p, src_mode, s);
     if (p.tw == 16) return launch_wino_tw<16>(a, p, src_mode, s);
     return launch_wino_tw<8>(a, p, src_mode, s);
 }
 
 }  // namespace pnp
+
+#ifdef PNP_STAMPS
+extern "C" int pnp_debug_stamps_reset(void) { pnp::g_stamp_slot = 0; return 0; }
+extern "C" int pnp_debug_stamps_read(unsigned long long* dst, int slots) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pnp::g_wino_stamps),
+                                    (size_t)slots * PNP_STAMP_WGS * PNP_STAMP_N * sizeof(unsigned long long));
+}
+#endif
