@@ -69,6 +69,21 @@ def main():
         print(f"{l.key:28s} {l.cin:4d} {l.cout:4d} {nch:6d} {d(0, 1):7.0f} {d(1, 2):7.0f} {(ch[:, 0, 1] - ch[:, 0, 0]).mean():6.0f} {commit:11.0f} "
               f"{transf:7.0f} {mfma:7.0f} {d(e, e + 1):7.0f} {d(e + 1, e + 2):7.0f} {d(e + 2, e + 3):7.0f} {d(e + 3, e + 4):7.0f} "
               f"{d(e + 4, e + 5):7.0f} {life:8.0f} {nmfma * 64 / life:6.3f}")
+        if os.environ.get("STAMPS_PLACEMENT"):
+            hw = (b[ok][:, NST - 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            xcc = (b[ok][:, NST - 2] & np.uint64(0xF)).astype(np.int64)
+            cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 0x7
+            key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+            wgs = np.nonzero(ok)[0]
+            t0 = t[:, 2]
+            groups = {}
+            for w, kk, tt in zip(wgs, key, t0):
+                groups.setdefault(int(kk), []).append((int(w), int(tt)))
+            print(f"{'':28s} {len(groups)} distinct CUs for {len(wgs)} workgroups; first CUs: " +
+                  "; ".join(f"cu{k}: " + ",".join(f"wg{w}@{(tt - min(x[1] for x in v)):d}" for w, tt in v) for k, v in list(sorted(groups.items()))[:6]))
+        if os.environ.get("STAMPS_PER_CHUNK"):
+            for nm, j0, j1 in (("wait+commit", 0, 1), ("transform", 1, 2), ("mfma", 2, 3)):
+                print(f"{'':28s} {nm:12s} per chunk: " + " ".join(f"{v:.0f}" for v in (ch[:, :, j1] - ch[:, :, j0]).mean(axis=0)))
 
 
 if __name__ == "__main__":
