@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 from dt4image_restoration_amd import synthetic, unet_spec, weights  # noqa: E402
 from dt4image_restoration_amd.engine import PnPEngine  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 
 
@@ -200,6 +201,21 @@ def main():
                                               if k not in ("layers", "conv3x3_mfma")},
             },
         }
+        # data-fidelity stage (fft_rows fwd + fft_cols_prox + fft_rows inv): HBM-bound; SURVEY 8(d): 37 B/px/iteration
+        fft_ms = (prof["fft_rows"]["ms"] + prof["fft_cols_prox"]["ms"]) / steps
+        if fft_ms > 0:
+            alg = 37.0 * n * h * w
+            moved = 81.0 * n * h * w          # + the two round trips of the complex scratch between the three passes
+            out["roofline_fft"] = {
+                "kernel": "fft_rows_kernel<1> + fft_cols_kernel<1> + fft_rows_kernel<2> (3 launches/step)", "bound": "hbm",
+                "achieved": round(alg / (fft_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_step": int(alg), "kernel_ms_per_step": round(fft_ms, 4),
+                "moved_gbs": round(moved / (fft_ms * 1e-3) / 1e9, 1),
+                "note": "achieved = algorithmic 37 B/px (x 4 + u 8 + y0 8 + mask 1 read, z 8 + u 8 written) / kernel time; the "
+                        "three LDS-resident passes actually move 81 B/px (two round trips of the complex scratch, which a "
+                        "256x256 slice = 512 KiB > LDS cannot avoid) = moved_gbs",
+            }
         if args.dump_layers:
             rows = []
             for l, ms, cnt in zip(unet_spec.UNET_LAYERS, prof["layers"]["ms"], prof["layers"]["launches"]):

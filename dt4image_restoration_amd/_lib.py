@@ -35,6 +35,9 @@ SIGNATURES = {
     "pnp_fft2c": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "pnp_prox_dual": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _vp]),
     "pnp_psnr": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _vp]),
+    "pnp_snapshot_bytes": (C.c_size_t, [C.c_void_p]),
+    "pnp_snapshot": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "pnp_restore": (C.c_int, [C.c_void_p, _vp, _fp, _fp, _fp, _fp, _vp]),
     "pnp_unet_read_stage": (C.c_int, [C.c_void_p, C.c_int, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), _vp]),
     "pnp_profile_reset": (C.c_int, [C.c_void_p]),

@@ -399,6 +399,38 @@ int pnp_psnr(pnp_handle e, const float* x, const float* gt, float* out, void* st
     return PNP_OK;
 }
 
+size_t pnp_snapshot_bytes(pnp_handle e) {
+    if (!e) return 0;
+    const size_t px = (size_t)e->cfg.n * e->cfg.h * e->cfg.w;
+    return px * (4 + 8 + 8) + (size_t)e->cfg.n * 4;
+}
+
+int pnp_snapshot(pnp_handle e, const float* x, const float* z, const float* u, const float* t_state, void* dst,
+                 void* stream) {
+    if (!e || !x || !z || !u || !dst) return fail(PNP_ERR_INVALID, "pnp_snapshot: null argument");
+    const size_t px = (size_t)e->cfg.n * e->cfg.h * e->cfg.w;
+    char* d = static_cast<char*>(dst);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(d, x, px * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + px * 4, z, px * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + px * 12, u, px * 8, hipMemcpyDeviceToDevice, s));
+    if (t_state) HIP_TRY(hipMemcpyAsync(d + px * 20, t_state, (size_t)e->cfg.n * 4, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(d + px * 20, 0, (size_t)e->cfg.n * 4, s));
+    return PNP_OK;
+}
+
+int pnp_restore(pnp_handle e, const void* src, float* x, float* z, float* u, float* t_state, void* stream) {
+    if (!e || !x || !z || !u || !src) return fail(PNP_ERR_INVALID, "pnp_restore: null argument");
+    const size_t px = (size_t)e->cfg.n * e->cfg.h * e->cfg.w;
+    const char* d = static_cast<const char*>(src);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(x, d, px * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(z, d + px * 4, px * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(u, d + px * 12, px * 8, hipMemcpyDeviceToDevice, s));
+    if (t_state) HIP_TRY(hipMemcpyAsync(t_state, d + px * 20, (size_t)e->cfg.n * 4, hipMemcpyDeviceToDevice, s));
+    return PNP_OK;
+}
+
 int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, int* ww, void* stream) {
     if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
     if (which == 8 && e->fuse_last) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 8 is fused away; create the handle with PNP_FLAG_KEEP_STAGES");

@@ -141,6 +141,33 @@ class PnPEngine:
         _lib.check(self.lib.pnp_psnr(self._h, x.data_ptr(), gt.data_ptr(), out.data_ptr(), _stream()), "pnp_psnr")
         return out
 
+    def snapshot(self, x: torch.Tensor, z: torch.Tensor, u: torch.Tensor, t_state: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One packed device buffer [x | z | u | T] (pnp_snapshot): a tree-search node's copy of the iterate."""
+        nhw = self.n * self.h * self.w
+        self._chk(x, torch.float32, nhw, "x"); self._chk(z, torch.complex64, nhw, "z"); self._chk(u, torch.complex64, nhw, "u")
+        if t_state is not None:
+            self._chk(t_state, torch.float32, self.n, "t_state")
+        nbytes = self.lib.pnp_snapshot_bytes(self._h)
+        if out is None:
+            out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        elif out.numel() * out.element_size() != nbytes or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"snapshot buffer must be {nbytes} contiguous bytes on {self.device}")
+        _lib.check(self.lib.pnp_snapshot(self._h, x.data_ptr(), z.data_ptr(), u.data_ptr(), _ptr(t_state), out.data_ptr(),
+                                         _stream()), "pnp_snapshot")
+        return out
+
+    def restore(self, snap: torch.Tensor, x: torch.Tensor, z: torch.Tensor, u: torch.Tensor,
+                t_state: Optional[torch.Tensor] = None) -> None:
+        nhw = self.n * self.h * self.w
+        self._chk(x, torch.float32, nhw, "x"); self._chk(z, torch.complex64, nhw, "z"); self._chk(u, torch.complex64, nhw, "u")
+        if t_state is not None:
+            self._chk(t_state, torch.float32, self.n, "t_state")
+        if snap.numel() * snap.element_size() != self.lib.pnp_snapshot_bytes(self._h) or not snap.is_contiguous():
+            raise ValueError("not a snapshot of this engine")
+        _lib.check(self.lib.pnp_restore(self._h, snap.data_ptr(), x.data_ptr(), z.data_ptr(), u.data_ptr(), _ptr(t_state),
+                                        _stream()), "pnp_restore")
+
     def read_stage(self, which: int) -> torch.Tensor:
         c, hh, ww = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.lib.pnp_unet_read_stage(self._h, which, None, C.byref(c), C.byref(hh), C.byref(ww), _stream()),

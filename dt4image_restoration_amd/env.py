@@ -120,11 +120,18 @@ class PnPEnv:
         return float(self.no_ref_model(state["x"]))
 
     # ---- explicit state copies (the reference rebinds tensors; this engine updates in place) ----
-    @staticmethod
-    def snapshot(states) -> Dict[str, torch.Tensor]:
+    def snapshot(self, states) -> Dict[str, torch.Tensor]:
+        """A node's copy of the iterate.  Whole-batch states of the live engine go through pnp_snapshot into one packed
+        device buffer; anything else (row slices, states of another size) is cloned tensor by tensor."""
+        e = self._engine
+        if (e is not None and states["x"].numel() == e.n * e.h * e.w and states["T"].numel() == e.n
+                and states["T"].dtype == torch.float32 and states["T"].is_contiguous()):
+            return {"packed": e.snapshot(states["x"], states["z"], states["u"], states["T"])}
         return {k: states[k].clone() for k in ("x", "z", "u", "T")}
 
-    @staticmethod
-    def restore(states, snap) -> None:
+    def restore(self, states, snap) -> None:
+        if "packed" in snap:
+            self._engine.restore(snap["packed"], states["x"], states["z"], states["u"], states["T"])
+            return
         for k in ("x", "z", "u", "T"):
             states[k].copy_(snap[k])

@@ -114,6 +114,18 @@ int pnp_prox_dual(pnp_handle h, const float* mu, const float* t_action, const fl
  * 10*log10(1/mean((clamp(x,0,1)-gt)^2)).  x, gt DEVICE float32 [N,1,H,W]; out DEVICE float32 [N]. */
 int pnp_psnr(pnp_handle h, const float* x, const float* gt, float* out, void* stream);
 
+/* ---- tree search support --------------------------------------------------------------------- */
+
+/* Replaces: the per-child copy of `states` in expand_tree (evaluation/mcts.py:118-128), which the reference gets for
+ * free because every op in PnPEnv.step allocates fresh tensors (evaluation/env.py:85-93); here x/z/u are updated in
+ * place, so a node keeps its iterate as ONE packed device buffer: [x f32 N*H*W | z c64 N*H*W | u c64 N*H*W | t f32 N].
+ * The episode's k-space constants (pnp_reset) are shared by all nodes and not part of a snapshot.
+ * t_state may be NULL (zeros are stored / nothing restored).  Copies are asynchronous on `stream`. */
+size_t pnp_snapshot_bytes(pnp_handle h);
+int pnp_snapshot(pnp_handle h, const float* x, const float* z, const float* u, const float* t_state, void* dst,
+                 void* stream);
+int pnp_restore(pnp_handle h, const void* src, float* x, float* z, float* u, float* t_state, void* stream);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 
 /* Copy one internal activation of the LAST denoiser forward to `dst` (DEVICE float32, NCHW

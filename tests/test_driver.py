@@ -194,6 +194,37 @@ def test_mcts_mechanics_with_stub_scorer():
 
 
 @pytest.mark.gpu
+def test_mcts_at_256_with_five_children():
+    """BASELINE configs[3] geometry: 256x256 slice, the reference's 5 children per expansion (mcts.py:100) stepped as ONE
+    batch of 5 through the engine; seeded -> reproducible; the returned PSNR is that of the best leaf's image."""
+    import torch.nn.functional as F
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.drivers.mcts import MCTS
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=12.0))
+
+    def scorer(states):
+        x = states["x"]
+        return 1.0 / (1e-3 + ((x - F.avg_pool2d(x, 3, 1, 1)) ** 2).mean(dim=(1, 2, 3)))
+
+    problem = synthetic.make_problem(1, 256, 256, accel=4.0, seed=9)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+
+    def search():
+        ev = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), max_timesteps=6, device_type="cuda")
+        return MCTS(ev, scorer, n_children=5, rounds=3, seed=11).run(mat, torch.tensor([D.normalised_rtg(10.0)]),
+                                                                    torch.tensor([4]))
+    p1, root1 = search()
+    p2, _ = search()
+    assert float(p1) == float(p2)
+    assert len(root1.children) == 5 and root1.visits == 3
+    assert all(c.snap["x"].shape == (1, 1, 256, 256) for c in root1.children)
+    assert 15.0 < float(p1) < 45.0
+
+
+@pytest.mark.gpu
 def test_cli_subcommands_run_on_synthetic_data():
     from dt4image_restoration_amd import cli
     ev = cli.main(["--block_size", "18", "--n_embeds", "9", "--limit", "2", "eval", "--rtg", "10", "--max_timesteps", "5"])

@@ -86,7 +86,7 @@ def test_per_slice_stop_leaves_done_slices_bit_identical(denoiser):
     st = env.reset(_mat(synthetic.make_problem(3, 64, 64, seed=5)), "cuda")
     act = {"T": torch.zeros(3), "mu": torch.tensor([0.1, 0.2, 0.3]), "sigma_d": torch.tensor([0.05, 0.1, 0.15])}
     st, _ = env.step(st, act)
-    before = env.snapshot(st)
+    before = {k: st[k].clone() for k in ("x", "z", "u", "T")}
     act["T"] = torch.tensor([0.0, 0.9, 0.0])
     st, done = env.step(st, act)
     assert done.tolist() == [False, True, False]
@@ -137,6 +137,33 @@ def test_snapshot_restore_and_inplace_state(denoiser):
     st, _ = env.step(st, act)
     for k in a:
         assert torch.equal(a[k], st[k])
+
+
+def test_packed_snapshot_layout_matches_header(denoiser):
+    """pnp_snapshot (include/pnpadmm.h): one buffer [x f32 | z c64 | u c64 | T f32], bit copies; restore writes them back
+    and leaves the episode's k-space constants alone (the next step equals the step taken from the original state)."""
+    env = _env(denoiser)
+    st = env.reset(_mat(synthetic.make_problem(2, 64, 64, seed=8)), "cuda")
+    act = {"T": torch.zeros(2), "mu": torch.tensor([0.3, 0.1]), "sigma_d": torch.tensor([0.08, 0.12])}
+    st, _ = env.step(st, act)
+    snap = env.snapshot(st)
+    assert set(snap) == {"packed"}
+    buf = snap["packed"]
+    px = 2 * 64 * 64
+    assert buf.numel() == px * 20 + 2 * 4
+    assert torch.equal(buf[:px * 4].view(torch.float32), st["x"].reshape(-1))
+    assert torch.equal(buf[px * 4:px * 12].view(torch.float32), torch.view_as_real(st["z"]).reshape(-1))
+    assert torch.equal(buf[px * 12:px * 20].view(torch.float32), torch.view_as_real(st["u"]).reshape(-1))
+    assert torch.equal(buf[px * 20:].view(torch.float32), st["T"].reshape(-1))
+    st, _ = env.step(st, act)
+    ref = {k: st[k].clone() for k in ("x", "z", "u", "T")}
+    for k in ("x", "z", "u"):
+        st[k].zero_()
+    st["T"].fill_(7.0)
+    env.restore(st, snap)
+    st, _ = env.step(st, act)
+    for k in ref:
+        assert torch.equal(ref[k], st[k]), k
 
 
 def test_shim_error_behaviour(denoiser):
@@ -211,3 +238,30 @@ def test_full_size_batch64_properties(denoiser):
     dp = abs(float(O.psnr(so["x"], so["gt"])) - float(env.compute_reward(st["x"][:1], st["gt"][:1])))
     assert dp < PSNR_TOL_DB
     np.testing.assert_allclose(st["x"][:1].cpu().numpy(), so["x"].numpy(), rtol=0, atol=2e-5)
+
+
+# ---- BASELINE configs[4] geometry: 512x512, 8x undersampling (f32 path; the bf16 conv variant is a later round) ---------
+def test_512_accel8_matches_oracle_and_properties(denoiser):
+    from oracle import pnp_oracle as O
+    n, h, w = 3, 512, 512
+    data = synthetic.make_problem(n, h, w, accel=8.0, seed=4321)
+    assert 0.10 < float(np.asarray(data["mask"]).mean()) < 0.16            # ~1/8 of k-space sampled
+    mu_tab, sg_tab = synthetic.param_table(n, 3, seed=5)
+    env = _env(denoiser)
+    st = env.reset(_mat(data), "cuda")
+    for t in range(3):
+        u_prev = st["u"].clone()
+        st, _ = env.step(st, {"T": torch.zeros(n), "mu": torch.from_numpy(mu_tab[:, t].copy()),
+                              "sigma_d": torch.from_numpy(sg_tab[:, t].copy())})
+        assert float((st["u"] - (u_prev + st["x"] - st["z"])).abs().max()) < 1e-5            # env.py:93
+    assert bool(torch.isfinite(st["x"]).all()) and float(st["x"].min()) >= 0.0 and float(st["x"].max()) <= 1.0
+    sd = O.torch_weights(denoiser.weights)
+    d1 = {k: (v[1:2] if k != "mask" else v) for k, v in data.items()}
+    so = O.reset(d1)
+    for t in range(3):
+        so, _ = O.admm_step(sd, so, torch.from_numpy(mu_tab[1:2, t].copy()), torch.from_numpy(sg_tab[1:2, t].copy()))
+    dp = abs(float(O.psnr(so["x"], so["gt"])) - float(env.compute_reward(st["x"][1:2].contiguous(), st["gt"][1:2])[0]))
+    assert dp < PSNR_TOL_DB
+    # FLOAT TOLERANCE: f32 summation order (Winograd / tiling) over 3 iterations of the 27-layer network
+    np.testing.assert_allclose(st["x"][1:2].cpu().numpy(), so["x"].numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(torch.view_as_real(st["z"][1:2]).cpu().numpy(), torch.view_as_real(so["z"]).numpy(), rtol=0, atol=3e-5)
