@@ -101,32 +101,55 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     const size_t base = ((size_t)n * H + y0) * W;
     const int tot = rpb * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) tw[i] = twg[i];
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-        const int r = e / W, c = e - r * W;
-        float2 v;
-        if (MODE == 1) {
-            const float2 uu = u[base + e];
-            v = make_float2(x[base + e] + uu.x, uu.y);
-        } else {
-            v = in[base + (size_t)r * W + (c ^ shift_in)];
+    // global accesses in batches of NB independent requests per thread (a plain loop with a run-time trip count waits for
+    // every load before issuing the next: 8 serial HBM round trips per workgroup)
+    constexpr int NB = 8;
+    const int lw = 31 - __builtin_clz(W);                  // W is a power of two
+    for (int e0 = threadIdx.x; e0 < tot; e0 += NB * 256) {
+        float2 v[NB];
+        float xv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = e0 + k * 256;
+            if (e < tot) {
+                if (MODE == 1) { v[k] = u[base + e]; xv[k] = x[base + e]; }
+                else { const int r = e >> lw, c = e & (W - 1); v[k] = in[base + (size_t)r * W + (c ^ shift_in)]; }
+            }
         }
-        buf0[e] = v;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = e0 + k * 256;
+            if (e < tot) buf0[e] = MODE == 1 ? make_float2(xv[k] + v[k].x, v[k].y) : v[k];
+        }
     }
     __syncthreads();
     const bool inv = (MODE == 2) || (MODE == 0 && inverse);
     float2* res = inv ? fft_lines<true>(buf0, buf1, tw, W, rpb, W) : fft_lines<false>(buf0, buf1, tw, W, rpb, W);
     const float sc = rsqrtf((float)W);
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-        const int r = e / W, c = e - r * W;
-        float2 v = res[e];
-        v.x *= sc; v.y *= sc;
+    for (int e0 = threadIdx.x; e0 < tot; e0 += NB * 256) {
+        float2 uu[NB];
+        float xv[NB];
         if (MODE == 2) {
-            const size_t g = base + e;
-            const float2 uu = u[g];
-            out[g] = v;                                            // z
-            u[g] = make_float2(uu.x + x[g] - v.x, uu.y - v.y);     // u + x - z
-        } else {
-            out[base + (size_t)r * W + (c ^ shift_out)] = v;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int e = e0 + k * 256;
+                if (e < tot) { uu[k] = u[base + e]; xv[k] = x[base + e]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = e0 + k * 256;
+            if (e < tot) {
+                float2 v = res[e];
+                v.x *= sc; v.y *= sc;
+                if (MODE == 2) {
+                    out[base + e] = v;                                                   // z
+                    u[base + e] = make_float2(uu[k].x + xv[k] - v.x, uu[k].y - v.y);     // u + x - z
+                } else {
+                    const int r = e >> lw, c = e & (W - 1);
+                    out[base + (size_t)r * W + (c ^ shift_out)] = v;
+                }
+            }
         }
     }
 }
@@ -151,16 +174,27 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
     float2* img = data + (size_t)n * H * W;
     const int tot = cw * H;
     for (int i = threadIdx.x; i < H; i += blockDim.x) tw[i] = twg[i];
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-        const int r = e / cw, c = e - r * cw;
-        buf0[c * lstr + (r ^ shift_in)] = img[(size_t)r * W + x0 + c];
+    constexpr int NB = 8;                                  // independent global requests per thread and batch
+    const int lcw = 31 - __builtin_clz(cw);                // cw is a power of two
+    for (int e0 = threadIdx.x; e0 < tot; e0 += NB * 256) {
+        float2 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = e0 + k * 256;
+            if (e < tot) v[k] = img[(size_t)(e >> lcw) * W + x0 + (e & (cw - 1))];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = e0 + k * 256;
+            if (e < tot) buf0[(e & (cw - 1)) * lstr + ((e >> lcw) ^ shift_in)] = v[k];
+        }
     }
     __syncthreads();
     const float sc = rsqrtf((float)H);
     if (MODE == 0) {
         float2* res = inverse ? fft_lines<true>(buf0, buf1, tw, H, cw, lstr) : fft_lines<false>(buf0, buf1, tw, H, cw, lstr);
-        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-            const int r = e / cw, c = e - r * cw;
+        for (int e = threadIdx.x; e < tot; e += 256) {
+            const int r = e >> lcw, c = e & (cw - 1);
             float2 v = res[c * lstr + (r ^ shift_out)];
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
@@ -172,22 +206,37 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
         const float inv1m = 1.f + m;
         const float2* y0n = y0s + (size_t)n * H * W;
         const uint8_t* mk = masks + (mask_n > 1 ? (size_t)n * H * W : 0);
-        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-            const int r = e / cw, c = e - r * cw;
-            float2 v = res[c * lstr + r];
-            v.x *= sc; v.y *= sc;                               // now the orthonormal FFT2 of x + u
-            const size_t g = (size_t)r * W + x0 + c;
-            if (mk[g]) {                                        // sampled k-space bin: closed-form solve
-                const float2 yy = y0n[g];
-                v.x = (m * v.x + yy.x) / inv1m;
-                v.y = (m * v.y + yy.y) / inv1m;
+        for (int e0 = threadIdx.x; e0 < tot; e0 += NB * 256) {
+            float2 yy[NB];
+            uint8_t mm[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {                      // mask and y0 of the batch in flight together; y0 is read for
+                const int e = e0 + k * 256;                     // unsampled bins too (a radial mask leaves < 1 % of the 128-B
+                if (e < tot) {                                  // lines untouched, so predicating it saves nothing)
+                    const size_t g = (size_t)(e >> lcw) * W + x0 + (e & (cw - 1));
+                    mm[k] = mk[g];
+                    yy[k] = y0n[g];
+                }
             }
-            res[c * lstr + r] = v;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int e = e0 + k * 256;
+                if (e < tot) {
+                    const int r = e >> lcw, c = e & (cw - 1);
+                    float2 v = res[c * lstr + r];
+                    v.x *= sc; v.y *= sc;                       // now the orthonormal FFT2 of x + u
+                    if (mm[k]) {                                // sampled k-space bin: closed-form solve
+                        v.x = (m * v.x + yy[k].x) / inv1m;
+                        v.y = (m * v.y + yy[k].y) / inv1m;
+                    }
+                    res[c * lstr + r] = v;
+                }
+            }
         }
         __syncthreads();
         float2* r2 = fft_lines<true>(res, oth, tw, H, cw, lstr);
-        for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-            const int r = e / cw, c = e - r * cw;
+        for (int e = threadIdx.x; e < tot; e += 256) {
+            const int r = e >> lcw, c = e & (cw - 1);
             float2 v = r2[c * lstr + r];
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
