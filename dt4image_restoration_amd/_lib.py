@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("PNP_LIB_PATH") or os.path.join(_HERE, "csrc", "libpnp
 PNP_FLAG_PROFILE = 1
 PNP_FLAG_NO_DENOISER = 2
 PNP_FLAG_KEEP_STAGES = 4
+PNP_FLAG_BF16_CONVS = 8
 PROFILE_CLASSES = 6
 PROFILE_CLASS_NAMES = ("conv3x3_mfma", "conv_first", "conv_last", "fft_rows", "fft_cols_prox", "other")
 N_LAYERS = 28

@@ -20,6 +20,7 @@
 //   * epilogue: + bias, LeakyReLU(0.2), NHWC store (two full 128-B lines per store instruction)
 #include "pnp_internal.h"
 #include "conv_staging.h"
+#include <cstring>
 
 namespace pnp {
 
@@ -43,7 +44,7 @@ const LayerSpec kLayers[N_LAYERS] = {
 // cannot hide its own LDS/global loads under it, so the k-loop rate is set by loads per MFMA: a 2x1 register
 // tile (MT x NT blocks of 32x32) runs at 74 cycles/MFMA, 2x2 at 69, 4x1 at 67.6, 4x2 at 66.2, 4x4 at 65.0 (64 is
 // the pipe).  So every config uses MT = 4 and the widest NT that Cout and the CU count allow.
-ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout) {
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16) {
     ConvPlan p{};
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     const long pixels = (long)N * H * W;
@@ -51,7 +52,7 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout) {
     p.splitk = 1;
     if (Cout == 32) { p.mt = 2; p.nt = 1; p.wm = 4; p.wn = 1; p.ck = 32; }    // short K, 128-B pixels: small tile, 3 workgroups/CU
     else if (Cout == 64) { p.nt = 2; p.wm = 4; p.wn = 1; p.ck = 16; }
-    else if (Cout % 256 == 0 && pixels / 256 * (Cout / 256) >= 256) { p.nt = 4; p.wm = 2; p.wn = 2; p.ck = 32; }
+    else if (!bf16 && Cout % 256 == 0 && pixels / 256 * (Cout / 256) >= 256) { p.nt = 4; p.wm = 2; p.wn = 2; p.ck = 32; }
     else { p.nt = 2; p.wm = 2; p.wn = 2; p.ck = 32; }
     auto finish = [&]() {
         p.bm = p.wm * p.mt * 32;
@@ -98,15 +99,55 @@ void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* d
     for (int i = 0; i < 1024; ++i) dst[o++] = 0.f;
 }
 
+// bf16 variant (PNP_FLAG_BF16_CONVS): 16-byte units [cout/32][cin/ck][tap 9][s ck/16][lane 64]; lane l (n = l&31, h = l>>5)
+// holds W[32*cb + n][ck*chunk + 16*s + 8*h + j][ky][kx], j = 0..7, rounded to bf16 (round to nearest even): the B operand
+// of v_mfma_f32_32x32x16_bf16 for k-step (chunk, tap, s).  Same float count bound as the f32 pack (half of it used).
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, float* dst_f) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+    size_t o = 0;
+    for (int cb = 0; cb < cout / 32; ++cb)
+        for (int ch = 0; ch < cin / ck; ++ch)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int s = 0; s < ck / 16; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * cb + (l & 31);
+                            const int ci = ck * ch + 16 * s + 8 * (l >> 5) + j;
+                            dst[o++] = f32_to_bf16_rne(oihw[((size_t)co * cin + ci) * 9 + tap]);
+                        }
+    for (int i = 0; i < 8192; ++i) dst[o++] = 0;          // 16 k-steps of zeros for the prefetch tail (PFD <= 9)
+}
+
 // One workgroup (4 waves) = one TH x TW pixel tile of one slice x BN output channels; wave (wm, wn) owns a
 // MT x NT register tile of 32x32 MFMA blocks (32*MT pixels x 32*NT channels).  Per CK-channel chunk:
 //     barrier | registers -> LDS patch (input transform applied) | barrier | issue next chunk's loads | k-loop
 // The next chunk's global loads are issued BEFORE the k-loop and consumed after it, so HBM latency sits under
 // thousands of MFMA cycles; 2-3 workgroups per CU cover each other's barriers, LDS writes and epilogues.
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK>
+//
+// BF16 = true (PNP_FLAG_BF16_CONVS, BASELINE configs[4]): the patch is rounded to bf16 as it is committed to LDS and the
+// k-loop runs on v_mfma_f32_32x32x16_bf16 (f32 accumulate): one MFMA per (M-block, N-block) and 16-channel k-step instead
+// of four per 8 channels.  Activations in HBM, input transforms, bias and epilogue stay f32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK, bool BF16>
 __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a) {
-    constexpr int CKP = CK + 4;        // padded pixel stride in LDS (floats): b128 lane groups hit 16 distinct slots
-    constexpr int KS = 9 * (CK / 8);   // k-steps (of 8 channels) per chunk
+    // padded pixel stride in LDS (floats): b128 lane groups hit 16 distinct slots (f32: CK + 4; bf16: CK + 8 halves)
+    constexpr int CKP = BF16 ? (CK + 8) / 2 : CK + 4;
+    constexpr int KCH = BF16 ? 16 : 8; // channels per k-step
+    constexpr int KS = 9 * (CK / KCH); // k-steps per chunk
+    // B fragments in flight (k-steps ahead).  PFD must divide KS (18 or 36 / 9 or 18) so that a chunk's k-step j always sits
+    // in slot j % PFD; a bf16 k-step is only MT*NT*32 cycles of MFMA, so the small tiles look 9 k-steps ahead.
+    constexpr int PFD = BF16 ? (MT * NT <= 2 ? 9 : 3) : 2;
+    static_assert(KS % PFD == 0, "slot rotation must line up at chunk boundaries");
     constexpr int PPP = CK / 4;        // 16-byte pieces per pixel
     constexpr int BM = WM * MT * 32;   // pixels per workgroup tile
     constexpr int TH = BM / TW;
@@ -120,7 +161,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % TW == 0, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) float patch[PH * PW * CKP];
+    constexpr int BN_ = WN * NT * 32;
+    constexpr bool LDS_EPI = !SPLITK && (size_t)BM * (BN_ + 4) <= (size_t)PH * PW * (CK + 4);   // output tile fits in the f32 patch space
+    constexpr int LDS_FLOATS = (LDS_EPI && BM * (BN_ + 4) > PH * PW * CKP) ? BM * (BN_ + 4) : PH * PW * CKP;
+    __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,7 +208,14 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             if (idx < ITEMS) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
-                *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                if constexpr (BF16) {                     // round to nearest even, 4 channels = 8 bytes
+                    const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+                    const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+                    *reinterpret_cast<uint2*>(&patch[(py * PW + px) * CKP + part * 2]) =
+                        make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+                } else {
+                    *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                }
             }
         }
     };
@@ -192,11 +243,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bias;
     }
 
-    // B fragments (weights, pre-packed per lane, L2-resident) run two k-steps ahead: slot ks & 1 is refilled with
-    // k-step ks + 2 right after the MFMAs of k-step ks; a k-step is 1000-4000 cycles of MFMA issue.
-    float4 bq[2][NT];
+    // B fragments (weights, pre-packed per lane, L2-resident) run PFD k-steps ahead: slot ks % PFD is refilled with
+    // k-step ks + PFD right after the MFMAs of k-step ks; an f32 k-step is 1000-4000 cycles of MFMA issue.
+    float4 bq[PFD][NT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PFD; ++p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bq[p][nt] = bptr[nt][p * 64];
 
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         for (int ks = 0; ks < KS; ++ks) {
             float4 a1[MT];
             if (ks + 1 < KS) {                                       // A fragments of the next k-step (LDS)
-                const int tap1 = (ks + 1) / (CK / 8), s1 = (ks + 1) % (CK / 8);
+                const int tap1 = (ks + 1) / (CK / KCH), s1 = (ks + 1) % (CK / KCH);
                 const int off1 = ((tap1 / 3) * PW + (tap1 % 3)) * CKP + 8 * s1;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a1[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt] + off1]);
@@ -230,15 +281,24 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             __builtin_amdgcn_sched_barrier(0);
 #define PNP_MFMA_ROUND(comp)                                                                                     \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)          \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].comp, bq[ks & 1][nt].comp, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].comp, bq[ks % PFD][nt].comp, acc[mt][nt], 0, 0, 0);
+            if constexpr (BF16) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
+                                                                              __builtin_bit_cast(bf16x8, bq[ks % PFD][nt]), acc[mt][nt], 0, 0, 0);
+            } else {
             PNP_MFMA_ROUND(x)
             PNP_MFMA_ROUND(y)
             PNP_MFMA_ROUND(z)
             PNP_MFMA_ROUND(w)
+            }
 #undef PNP_MFMA_ROUND
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[ks & 1][nt] = bp[nt][(ks + 2) * 64];   // refill the slot just read
+            for (int nt = 0; nt < NT; ++nt) bq[ks % PFD][nt] = bp[nt][(ks + PFD) * 64];   // refill the slot just read
             if (ks + 1 < KS) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
@@ -249,7 +309,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     // ---- epilogue: LeakyReLU(0.2) and NHWC store.
     constexpr int BN = WN * NT * 32;
     constexpr int OSTR = BN + 4;
-    constexpr bool LDS_EPI = !SPLITK && (size_t)BM * OSTR <= (size_t)PH * PW * CKP;   // output tile fits in the patch space
     if constexpr (LDS_EPI) {
         // Through LDS, so the global stores are 16 B per lane over whole pixels (a 4-B-per-lane store tail is
         // store-issue-bound) and the 2x2 max-pooled copy for the next stage can be written from the same tile.
@@ -349,47 +408,55 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK>
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, bool BF16>
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
     constexpr int WPS = MT * NT <= 2 ? 3 : (MT * NT <= 8 ? 2 : 1);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, bool SPLITK>
+template <int TW, int MT, int NT, int WM, int WN, int CK, bool SPLITK, bool BF16>
 static hipError_t launch_cfg(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
     switch (src_mode) {
-        case SRC_PLAIN: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_PLAIN, SPLITK>(a, p, s);
-        case SRC_POOL:  return launch_inst<TW, MT, NT, WM, WN, CK, SRC_POOL, SPLITK>(a, p, s);
-        case SRC_UPCAT: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_UPCAT, SPLITK>(a, p, s);
+        case SRC_PLAIN: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_PLAIN, SPLITK, BF16>(a, p, s);
+        case SRC_POOL:  return launch_inst<TW, MT, NT, WM, WN, CK, SRC_POOL, SPLITK, BF16>(a, p, s);
+        case SRC_UPCAT: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_UPCAT, SPLITK, BF16>(a, p, s);
         default: return hipErrorInvalidValue;
     }
 }
 
-template <int TW>
+template <int TW, bool BF16>
 static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
-    if (p.mt == 2 && p.wn == 4) return launch_cfg<TW, 2, 1, 1, 4, 32, true>(a, p, src_mode, s);    // small problems
-    if (p.mt == 2 && p.wn == 2) return launch_cfg<TW, 2, 1, 2, 2, 32, true>(a, p, src_mode, s);
-    if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32, false>(a, p, src_mode, s);
-    if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16, false>(a, p, src_mode, s);
-    if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32, false>(a, p, src_mode, s);
-    return launch_cfg<TW, 4, 4, 2, 2, 32, false>(a, p, src_mode, s);
+    if (p.mt == 2 && p.wn == 4) return launch_cfg<TW, 2, 1, 1, 4, 32, true, BF16>(a, p, src_mode, s);    // small problems
+    if (p.mt == 2 && p.wn == 2) return launch_cfg<TW, 2, 1, 2, 2, 32, true, BF16>(a, p, src_mode, s);
+    if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32, false, BF16>(a, p, src_mode, s);
+    if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16, false, BF16>(a, p, src_mode, s);
+    if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32, false, BF16>(a, p, src_mode, s);
+    if constexpr (BF16) return hipErrorInvalidValue;       // the bf16 plan never picks the 256-accumulator tile
+    else return launch_cfg<TW, 4, 4, 2, 2, 32, false, false>(a, p, src_mode, s);
 }
 
 hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
     if (a0.Cin % 32 != 0 || a0.Cout % 32 != 0 || (a0.Cout > 64 && a0.Cout % 128 != 0)) return hipErrorInvalidValue;
-    const ConvPlan p = conv3x3_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout);
+    const bool bf16 = a0.bf16 != 0;
+    const ConvPlan p = conv3x3_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout, bf16);
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
     const bool split = p.mt == 2 && p.wn >= 2;           // the small-problem configs always go through the workspace
     if (split && a.partial == nullptr) return hipErrorInvalidValue;
     hipError_t e;
-    if (p.tw == 32) e = launch_tw<32>(a, p, src_mode, s);
-    else if (p.tw == 16) e = launch_tw<16>(a, p, src_mode, s);
-    else e = launch_tw<8>(a, p, src_mode, s);
+    if (bf16) {
+        if (p.tw == 32) e = launch_tw<32, true>(a, p, src_mode, s);
+        else if (p.tw == 16) e = launch_tw<16, true>(a, p, src_mode, s);
+        else e = launch_tw<8, true>(a, p, src_mode, s);
+    } else {
+        if (p.tw == 32) e = launch_tw<32, false>(a, p, src_mode, s);
+        else if (p.tw == 16) e = launch_tw<16, false>(a, p, src_mode, s);
+        else e = launch_tw<8, false>(a, p, src_mode, s);
+    }
     if (e != hipSuccess || !split) return e;
     const size_t plane4 = (size_t)a.N * a.H * a.W * a.Cout / 4;
     unsigned blocks = (unsigned)((plane4 + 255) / 256);
@@ -400,13 +467,13 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
 }
 
 // The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
-bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout) {   // also: can fuse the last layer
-    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout);
+bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout, bool bf16) {   // also: can fuse the last layer
+    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout, bf16);
     return p.splitk == 1 && p.mt == 2 && p.nt == 1 && p.wm == 4;
 }
 
-size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout) {
-    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout);
+size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout, bool bf16) {
+    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout, bf16);
     return (p.mt == 2 && p.wn >= 2) ? (size_t)p.splitk * N * H * W * Cout : 0;
 }
 

@@ -130,6 +130,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         ConvArgs a{};
         a.pooled = pooled;
         a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
+        a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
             const int hs = a.H / 2, ws = a.W / 2;
@@ -170,6 +171,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         const LayerSpec& L = kLayers[26];
         ConvArgs a{};
         a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
+        a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
         Prof p(e, s, 0, 26);
@@ -206,7 +208,7 @@ int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float
 extern "C" {
 
 const char* pnp_last_error(void) { return g_err.c_str(); }
-const char* pnp_version(void) { return "pnpadmm 0.1 (gfx950, f32 MFMA)"; }
+const char* pnp_version(void) { return "pnpadmm 0.2 (gfx950, f32 MFMA; optional bf16-operand convs)"; }
 
 int pnp_create(const pnp_config* cfg, pnp_handle* out) {
     if (!cfg || !out) return fail(PNP_ERR_INVALID, "pnp_create: null argument");
@@ -241,7 +243,8 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
         size_t pf = 0;
         for (int li = 1; li < N_LAYERS - 1; ++li) {
             const LayerSpec& L = kLayers[li];
-            const size_t f = conv3x3_partial_floats(cfg->n, cfg->h >> L.level, cfg->w >> L.level, L.cin, L.cout);
+            const size_t f = conv3x3_partial_floats(cfg->n, cfg->h >> L.level, cfg->w >> L.level, L.cin, L.cout,
+                                                    (cfg->flags & PNP_FLAG_BF16_CONVS) != 0);
             if (f > pf) pf = f;
         }
         if (pf > 0) {
@@ -300,7 +303,8 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         } else {
             const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
             const WinoPlan wp = winograd_plan(e->cfg.n, lh, lw, L.cin, L.cout);
-            e->wino[li] = wp.use && getenv("PNP_NO_WINOGRAD") == nullptr;
+            const bool bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0;
+            e->wino[li] = wp.use && !bf16 && getenv("PNP_NO_WINOGRAD") == nullptr;
             if (e->wino[li]) {
                 pf = winograd_pack_floats(L.cin, L.cout);
                 tmp.resize(pf);
@@ -308,7 +312,9 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
             } else {
                 pf = conv3x3_pack_floats(L.cin, L.cout);
                 tmp.resize(pf);
-                pack_conv3x3_weights(w, L.cin, L.cout, conv3x3_plan(e->cfg.n, lh, lw, L.cin, L.cout).ck, tmp.data());
+                const int ck = conv3x3_plan(e->cfg.n, lh, lw, L.cin, L.cout, bf16).ck;
+                if (bf16) pack_conv3x3_weights_bf16(w, L.cin, L.cout, ck, tmp.data());
+                else pack_conv3x3_weights(w, L.cin, L.cout, ck, tmp.data());
             }
             src = tmp.data();
         }
@@ -323,9 +329,9 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
         const int li = 3 * k + 2;
         const LayerSpec& L = kLayers[li];
         const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
-        e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout));
+        e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout, (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0));
     }
-    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout));
+    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout, (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0));
     e->weights_loaded = true;
     return PNP_OK;
 }

@@ -32,6 +32,7 @@ struct ConvArgs {
     int Cin, Cskip, Cout;
     int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
+    int bf16;            // direct kernel: bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate
 #ifdef PNP_STAMPS
     int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
 #endif
@@ -50,14 +51,15 @@ struct ConvPlan {
     int splitk;        // K ranges (of whole chunks), one workgroup each; > 1 only on small problems
     int tiles_x, tiles_y;
 };
-ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout);
-size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout);
-bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout);
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
+size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
+bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
 
 // Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
 // layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.
 size_t conv3x3_pack_floats(int cin, int cout);
 void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* dst);
+void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, float* dst);   // same buffer size bound
 
 // Winograd F(2x2,3x3) path for the K-heavy layers (winograd_kernels.hip).
 struct WinoPlan {

@@ -14,21 +14,25 @@ from .weights import check_state_dict, generate_unet_weights
 
 
 class UNetDenoiser2D:
-    def __init__(self, ckpt_path: Optional[str] = None, state_dict: Optional[Mapping[str, object]] = None):
+    def __init__(self, ckpt_path: Optional[str] = None, state_dict: Optional[Mapping[str, object]] = None,
+                 bf16_convs: bool = False):
         """ckpt_path: a `torch.save`d state_dict with the reference's 56 keys (noise.py:146-148).
         state_dict: the same mapping given directly (tensors or ndarrays).
-        With neither, the reference raises ValueError (noise.py:143-145); so does this."""
+        With neither, the reference raises ValueError (noise.py:143-145); so does this.
+        bf16_convs: BASELINE configs[4] - conv operands rounded to bfloat16, f32 accumulate (PNP_FLAG_BF16_CONVS);
+        NOT the reference's arithmetic, off by default."""
         if state_dict is None:
             if ckpt_path is None:
                 raise ValueError("Default ckpt not found, you have to provide a ckpt path")
             state_dict = torch.load(ckpt_path, map_location="cpu")
         self.weights: Dict[str, np.ndarray] = check_state_dict(state_dict)
         self._engines: Dict[Tuple[int, int, int, int], PnPEngine] = {}
+        self.bf16_convs = bool(bf16_convs)
 
     @classmethod
-    def seeded(cls, seed: int = 0, init: str = "unit_gain") -> "UNetDenoiser2D":
+    def seeded(cls, seed: int = 0, init: str = "unit_gain", bf16_convs: bool = False) -> "UNetDenoiser2D":
         """Deterministic stand-in weights (the trained checkpoint is an external download)."""
-        return cls(state_dict=generate_unet_weights(seed, init))
+        return cls(state_dict=generate_unet_weights(seed, init), bf16_convs=bf16_convs)
 
     # nn.Module-shaped no-ops the reference's callers use (env.py:33 `.to(device_type)`)
     def to(self, *_a, **_k):
@@ -41,7 +45,7 @@ class UNetDenoiser2D:
         key = (n, h, w, device_index)
         eng = self._engines.get(key)
         if eng is None:
-            eng = PnPEngine(n, h, w, device=device_index)
+            eng = PnPEngine(n, h, w, device=device_index, bf16_convs=self.bf16_convs)
             eng.load_weights(self.weights)
             self._engines[key] = eng
         return eng

@@ -52,6 +52,12 @@ typedef struct {
 #define PNP_FLAG_NO_DENOISER 2   /* k-space-only handle (pnp_fft2c / pnp_psnr): no activation planes */
 #define PNP_FLAG_KEEP_STAGES 4   /* keep every U-Net stage output in memory for pnp_unet_read_stage (disables the
                                     fusion of the last 1x1 layer into the preceding conv's epilogue) */
+#define PNP_FLAG_BF16_CONVS 8    /* BASELINE configs[4]: the 26 conv3x3 layers with Cin >= 32 round their input patch and
+                                    weights to bfloat16 (nearest even) and run on v_mfma_f32_32x32x16_bf16 with f32
+                                    accumulation; activations in memory, bias, pooling, upsampling, the first and last
+                                    layer and the k-space stage stay f32.  NOT the reference's arithmetic: parity is
+                                    against the oracle's bf16-operand mode, and the PSNR offset to the f32 path is a
+                                    measured, stated bound */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 

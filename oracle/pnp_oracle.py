@@ -36,36 +36,48 @@ def _t(a, dtype):
     return torch.from_numpy(np.asarray(a)).to(dtype)
 
 
-def _stage(sd, prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """ConvBlock: 3 x [conv3x3 s1 p1 + bias, LeakyReLU(0.2)]  (evaluation/noise.py:88-98, 75-85)."""
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    """Round to bfloat16 (nearest even) and back: the operand rounding of the engine's PNP_FLAG_BF16_CONVS mode."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _stage(sd, prefix: str, x: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
+    """ConvBlock: 3 x [conv3x3 s1 p1 + bias, LeakyReLU(0.2)]  (evaluation/noise.py:88-98, 75-85).
+
+    bf16_operands (BASELINE configs[4], not the reference's arithmetic): every conv with Cin >= 32 sees its input tensor
+    and its weights rounded to bfloat16; products and sums stay in the working precision, bias is not rounded."""
     for j in range(3):
         w = sd[f"{prefix}.conv-{j}.conv2d.weight"]
         b = sd[f"{prefix}.conv-{j}.conv2d.bias"]
+        if bf16_operands and w.shape[1] >= 32:
+            x, w = _bf16(x), _bf16(w)
         x = F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), LEAKY)
     return x
 
 
-def _up(sd, prefix: str, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+def _up(sd, prefix: str, x1: torch.Tensor, x2: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
     """up.forward: bilinear x2 (align_corners=True), pad to the skip's size, cat([skip, up])
     then ConvBlock  (evaluation/noise.py:44-61)."""
     x1 = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
     dy = x2.shape[2] - x1.shape[2]
     dx = x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
-    return _stage(sd, prefix, torch.cat([x2, x1], dim=1))
+    return _stage(sd, prefix, torch.cat([x2, x1], dim=1), bf16_operands)
 
 
-def unet_forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, return_stages: bool = False):
+def unet_forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, return_stages: bool = False,
+                 bf16_operands: bool = False):
     """UNet(2,1).forward on [N,2,H,W]  (evaluation/noise.py:119-133)."""
-    x1 = _stage(sd, "inc.conv", x)
-    x2 = _stage(sd, "down1.mpconv.1", F.max_pool2d(x1, 2))
-    x3 = _stage(sd, "down2.mpconv.1", F.max_pool2d(x2, 2))
-    x4 = _stage(sd, "down3.mpconv.1", F.max_pool2d(x3, 2))
-    x5 = _stage(sd, "down4.mpconv.1", F.max_pool2d(x4, 2))
-    y1 = _up(sd, "up1.conv", x5, x4)
-    y2 = _up(sd, "up2.conv", y1, x3)
-    y3 = _up(sd, "up3.conv", y2, x2)
-    y4 = _up(sd, "up4.conv", y3, x1)
+    q = bf16_operands
+    x1 = _stage(sd, "inc.conv", x, q)
+    x2 = _stage(sd, "down1.mpconv.1", F.max_pool2d(x1, 2), q)
+    x3 = _stage(sd, "down2.mpconv.1", F.max_pool2d(x2, 2), q)
+    x4 = _stage(sd, "down3.mpconv.1", F.max_pool2d(x3, 2), q)
+    x5 = _stage(sd, "down4.mpconv.1", F.max_pool2d(x4, 2), q)
+    y1 = _up(sd, "up1.conv", x5, x4, q)
+    y2 = _up(sd, "up2.conv", y1, x3, q)
+    y3 = _up(sd, "up3.conv", y2, x2, q)
+    y4 = _up(sd, "up4.conv", y3, x1, q)
     residual = F.conv2d(y4, sd["outc.conv.weight"], sd["outc.conv.bias"])
     out = x[:, :1] + residual
     if return_stages:
@@ -73,12 +85,12 @@ def unet_forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, return_stages:
     return out
 
 
-def denoise(sd: Mapping[str, torch.Tensor], x: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+def denoise(sd: Mapping[str, torch.Tensor], x: torch.Tensor, sigma: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
     """UNetDenoiser2D.forward(x[N,1,H,W], sigma[N]) -> [N,1,H,W] in [0,1]
     (evaluation/noise.py:155-164)."""
     n, _, h, w = x.shape
     noise_map = torch.ones(n, 1, h, w, dtype=x.dtype) * sigma.reshape(n, 1, 1, 1).to(x.dtype)
-    return torch.clamp(unet_forward(sd, torch.cat([x, noise_map], dim=1)), 0, 1)
+    return torch.clamp(unet_forward(sd, torch.cat([x, noise_map], dim=1), bf16_operands=bf16_operands), 0, 1)
 
 
 def fft2c(img: torch.Tensor) -> torch.Tensor:
@@ -118,7 +130,7 @@ def reset(data: Mapping[str, np.ndarray], dtype=torch.float32) -> "OrderedDict[s
 
 
 def admm_step(sd: Mapping[str, torch.Tensor], st: "OrderedDict[str, torch.Tensor]",
-              mu: torch.Tensor, sigma_d: torch.Tensor, T: Optional[torch.Tensor] = None):
+              mu: torch.Tensor, sigma_d: torch.Tensor, T: Optional[torch.Tensor] = None, bf16_operands: bool = False):
     """PnPEnv.step  (evaluation/env.py:74-100), batched over N independent slices.
 
     The reference is hard-wired to N=1 with scalar mu; for N>1 the oracle is DEFINED as N
@@ -135,7 +147,7 @@ def admm_step(sd: Mapping[str, torch.Tensor], st: "OrderedDict[str, torch.Tensor
     if act.any():
         ia = act.nonzero().flatten()
         za, ua, y0a, mua = z[ia], u[ia], y0[ia], mu[ia]
-        xa = denoise(sd, (za - ua).real, sigma_d[ia])                 # env.py:85-86
+        xa = denoise(sd, (za - ua).real, sigma_d[ia], bf16_operands)  # env.py:85-86
         zf = fft2c(xa + ua)                                            # env.py:87
         temp = (mua * zf + y0a) / (1 + mua)                            # env.py:88-89
         zf = torch.where(mask, temp, zf)                               # env.py:90  z[mask] = temp[mask]
