@@ -156,15 +156,27 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     constexpr int PW = PWL;            // LDS row stride (pixels)
     constexpr int ITEMS = PH * PWL * PPP;        // 16-byte pieces per chunk
     constexpr int NIT = (ITEMS + 255) / 256;
-    constexpr bool PREFETCH = SRC == SRC_PLAIN;  // raw loads of the next chunk held in registers across the k-loop
+    // PLAIN chunks: the raw loads of the next chunk are held in registers across the k-loop.  UPCAT chunks that come from
+    // the bilinear x2 upsample (4 source pixels per patch pixel) do not fit in registers that way; instead the LOW-RES
+    // source region of the tile, (TH/2+3) x (TW/2+3) pixels, is prefetched like a PLAIN chunk, parked in LDS, and the
+    // patch is interpolated LDS -> LDS (same scheme as the Winograd kernel).  POOL sources (only used when no pooled copy
+    // exists) stage synchronously in batches.
+    constexpr bool UP2 = SRC == SRC_UPCAT;
+    constexpr bool PREFETCH = SRC == SRC_PLAIN || UP2;
     constexpr int LB = PREFETCH ? NIT : (NIT < 3 ? NIT : 3);   // pieces per batch when staging synchronously
+    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;            // low-res region bound (rows, cols)
+    constexpr int CKL = CK + 4;                                // its pixel stride (floats, always f32)
+    constexpr int LITEMS = LH * LW * PPP;
+    constexpr int NITL = (LITEMS + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % TW == 0, "tile shape");
 
     constexpr int BN_ = WN * NT * 32;
     constexpr bool LDS_EPI = !SPLITK && (size_t)BM * (BN_ + 4) <= (size_t)PH * PW * (CK + 4);   // output tile fits in the f32 patch space
-    constexpr int LDS_FLOATS = (LDS_EPI && BM * (BN_ + 4) > PH * PW * CKP) ? BM * (BN_ + 4) : PH * PW * CKP;
+    constexpr int PATCH_FLOATS = (LDS_EPI && BM * (BN_ + 4) > PH * PW * CKP) ? BM * (BN_ + 4) : PH * PW * CKP;
+    constexpr int LDS_FLOATS = PATCH_FLOATS + (UP2 ? LH * LW * CKL : 0);
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
+    float* const lowres = patch + PATCH_FLOATS;            // UPCAT: [LH][LW][CKL] low-res source region
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -186,7 +198,25 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     const int c_end = c_begin + cpb;
 
     // ---- staging helpers ------------------------------------------------------------------------------------
-    RawPiece<SRC> raw[PREFETCH ? NIT : LB];
+    auto store_patch = [&](int py, int px, int part, float4 v) {
+        if constexpr (BF16) {                             // round to nearest even, 4 channels = 8 bytes
+            const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+            const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+            *reinterpret_cast<uint2*>(&patch[(py * PW + px) * CKP + part * 2]) =
+                make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+        } else {
+            *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+        }
+    };
+    // UPCAT geometry of this tile: low-res rows/cols [ylo, ylo+LH) x [xlo, xlo+LW) cover every source pixel of the patch
+    const int Hs = a.H >> 1, Ws = a.W >> 1;
+    const int ylo = UP2 ? (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)) : 0;
+    const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
+    const int nskip = UP2 ? a.Cskip / CK : 0;             // leading chunks that come straight from the skip tensor
+
+    constexpr int LBS = NIT < 4 ? NIT : 4;               // skip-chunk pieces per synchronous batch (UPCAT)
+    RawPiece<SRC> raw[UP2 ? 1 : (PREFETCH ? NIT : LB)];
+    float4 rawu[UP2 ? (NITL > LBS ? NITL : LBS) : 1];
     auto issue = [&](int c, int it0, int cnt) {           // loads of pieces [it0, it0+cnt) of chunk c -> raw[0..cnt)
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
@@ -194,8 +224,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PWL, px = pp % PWL;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                issue_piece<SRC>(a, n, gy, gx, c * CK + part * 4, raw[k]);
+            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                if constexpr (UP2)                        // a skip chunk: one plain 16-byte piece
+                    rawu[k] = *reinterpret_cast<const float4*>(a.src0 + (((size_t)n * a.H + gy) * a.W + gx) * a.Cskip + c * CK + part * 4);
+                else
+                    issue_piece<SRC>(a, n, gy, gx, c * CK + part * 4, raw[k]);
+            }
         }
     };
     auto commit = [&](int c, int it0, int cnt) {          // transform raw[0..cnt) and write the LDS patch
@@ -207,20 +241,61 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             if (idx < ITEMS) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
-                if constexpr (BF16) {                     // round to nearest even, 4 channels = 8 bytes
-                    const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
-                    const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
-                    *reinterpret_cast<uint2*>(&patch[(py * PW + px) * CKP + part * 2]) =
-                        make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-                } else {
-                    *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    if constexpr (UP2) v = rawu[k];
+                    else v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
                 }
+                store_patch(py, px, part, v);
+            }
+        }
+    };
+    auto issue_lo = [&](int c) {                          // UPCAT: low-res region of upsampled chunk c -> rawu
+        const int Cup = a.Cin - a.Cskip;
+        const float* base = a.src1 + (size_t)n * Hs * Ws * Cup + (c * CK - a.Cskip);
+#pragma unroll
+        for (int k = 0; k < NITL; ++k) {
+            const int idx = tid + k * 256;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int sy = ylo + pp / LW, sx = xlo + pp % LW;
+            if (idx < LITEMS && sy < Hs && sx < Ws)
+                rawu[k] = *reinterpret_cast<const float4*>(base + ((size_t)sy * Ws + sx) * Cup + part * 4);
+        }
+    };
+    auto commit_lo = [&]() {
+        // park the low-res region in LDS, then interpolate the patch from it (ATen upsample_bilinear2d,
+        // align_corners=True: src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
+#pragma unroll
+        for (int k = 0; k < NITL; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKL + (idx % PPP) * 4]) = rawu[k];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * 256;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PWL, px = pp % PWL;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
+                    const int y0 = (int)sy, x0 = (int)sx;
+                    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+                    const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * CKL + part * 4];
+                    const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * CKL + part * 4];
+                    v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * CKL), *reinterpret_cast<const float4*>(r0 + x1 * CKL),
+                                *reinterpret_cast<const float4*>(r1 + x0 * CKL), *reinterpret_cast<const float4*>(r1 + x1 * CKL),
+                                1.f - lx, lx, 1.f - ly, ly);
+                }
+                store_patch(py, px, part, v);
             }
         }
     };
 
-    if (PREFETCH) issue(c_begin, 0, NIT);
+    if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); }
+    else if (PREFETCH) issue(c_begin, 0, NIT);
 
     // LDS float offset of this lane's A row for each of its M-blocks (tap (0,0), channel 4*hh)
     int aoff[MT];
@@ -253,14 +328,22 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 
     for (int c = c_begin; c < c_end; ++c) {
         if (c > c_begin) __syncthreads();      // every wave is done reading the previous chunk's patch
-        if (PREFETCH) {
+        if constexpr (UP2) {
+            if (c >= nskip) {
+                commit_lo();
+            } else {
+#pragma unroll 1
+                for (int it0 = 0; it0 < NIT; it0 += LBS) { issue(c, it0, LBS); commit(c, it0, LBS); }
+            }
+        } else if (PREFETCH) {
             commit(c, 0, NIT);
         } else {
 #pragma unroll 1
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
         __syncthreads();
-        if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT);
+        if constexpr (UP2) { if (c + 1 < c_end && c + 1 >= nskip) issue_lo(c + 1); }
+        else if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT);
 
         const float4* bp[NT];
 #pragma unroll
@@ -411,7 +494,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, bool BF16>
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
-    constexpr int WPS = MT * NT <= 2 ? 3 : (MT * NT <= 8 ? 2 : 1);
+    // (the UPCAT variant also holds the low-res source region in LDS: two workgroups per CU at most)
+    constexpr int WPS = (MT * NT <= 2 && SRC != SRC_UPCAT) ? 3 : (MT * NT <= 8 ? 2 : 1);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
