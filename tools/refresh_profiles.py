@@ -14,14 +14,14 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 tag, pmc = sys.argv[1], sys.argv[2]
 
-shutil.copy(glob.glob(f"{G}/prof_{tag}/runc/*_kernel_stats.csv")[0], f"{P}/r01_kernel_stats.csv")
+shutil.copy((glob.glob(f"{G}/prof_{tag}/runc/*_kernel_stats.csv") + glob.glob(f"{G}/prof_{tag}/*kernel_stats.csv"))[0], f"{P}/r01_kernel_stats.csv")
 shutil.copy(f"{G}/layers_{tag}.json", f"{P}/r01_layers.json")
 shutil.copy(f"{G}/bench_prof_{tag}.json", f"{P}/r01_bench_under_rocprof.json")
 shutil.copy(f"{G}/bench_{tag}.json", f"{P}/r01_bench.json")
 
 
 def load(d):
-    return list(csv.DictReader(open(glob.glob(f"{G}/{d}/runc/*_counter_collection.csv")[0])))
+    return list(csv.DictReader(open((glob.glob(f"{G}/{d}/runc/*_counter_collection.csv") + glob.glob(f"{G}/{d}/*counter_collection.csv"))[0])))
 
 
 out = {}
@@ -49,7 +49,7 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),
 
 rows = load(f"pmcS{pmc}")
 kt = {}
-for r in csv.DictReader(open(glob.glob(f"{G}/pmcS{pmc}/runc/*_kernel_trace.csv")[0])):
+for r in csv.DictReader(open((glob.glob(f"{G}/pmcS{pmc}/runc/*_kernel_trace.csv") + glob.glob(f"{G}/pmcS{pmc}/*kernel_trace.csv"))[0])):
     kt[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"])
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
