@@ -120,6 +120,34 @@ def test_prox_dual_matches_oracle(n, h, w):
     np.testing.assert_allclose(torch.view_as_real(ug.cpu()).numpy(), torch.view_as_real(un).numpy(), rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("h,w", [(64, 64), (128, 256), (256, 64)])
+def test_prox_dual_per_slice_masks_and_non_square(h, w):
+    """mask_n == N (the reference's z[mask] needs a mask of z's shape for N > 1): every slice its own sampling
+    pattern, on square and non-square power-of-two sizes; slice n of the batch == the oracle's single-slice solve."""
+    n = 3
+    datas = [synthetic.make_problem(1, h, w, accel=acc, seed=50 + i) for i, acc in enumerate((2.0, 4.0, 8.0))]
+    masks = torch.stack([torch.from_numpy(np.asarray(d["mask"])).reshape(h, w).bool() for d in datas])
+    assert not torch.equal(masks[0], masks[2])
+    y0 = torch.cat([torch.view_as_complex(torch.from_numpy(d["y0"])) for d in datas])
+    x0 = torch.cat([torch.view_as_complex(torch.from_numpy(d["x0"])) for d in datas])
+    e = _engine(n, h, w)
+    e.reset(x0.cuda(), y0.cuda(), masks.cuda())
+    xd = torch.clamp(x0.real + 0.05 * torch.from_numpy(synthetic.hash_uniform(9, 1, n * h * w).reshape(n, 1, h, w)), 0, 1)
+    u0 = 0.1 * torch.view_as_complex(torch.from_numpy(synthetic.hash_uniform(9, 2, 2 * n * h * w).reshape(n, 1, h, w, 2).copy()))
+    mu = torch.tensor([0.07, 0.3, 0.55])
+    xg, ug = xd.cuda(), u0.cuda().clone()
+    zg = torch.empty_like(ug)
+    e.prox_dual(xg, zg, ug, mu.cuda())
+    for i in range(n):
+        zf = O.fft2c(xd[i:i + 1] + u0[i:i + 1])
+        temp = (mu[i] * zf + y0[i:i + 1]) / (1 + mu[i])
+        zn = O.ifft2c(torch.where(masks[i].reshape(1, 1, h, w), temp, zf))
+        # FLOAT TOLERANCE: two f32 FFTs + pointwise, data O(1)
+        np.testing.assert_allclose(torch.view_as_real(zg[i:i + 1].cpu()).numpy(), torch.view_as_real(zn).numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(torch.view_as_real(ug[i:i + 1].cpu()).numpy(),
+                                   torch.view_as_real(u0[i:i + 1] + xd[i:i + 1] - zn).numpy(), rtol=0, atol=5e-6)
+
+
 def test_psnr_matches_oracle(golden_dir):
     n, h, w = 3, 64, 64
     e = _engine(n, h, w)
