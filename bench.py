@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--convs", choices=("f32", "bf16"), default="f32",
                     help="bf16: BASELINE configs[4]'s bf16-operand denoiser convs (PNP_FLAG_BF16_CONVS); not the headline line")
     ap.add_argument("--accel", type=float, default=4.0, help="undersampling factor of the radial mask (configs[4]: 8)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="experiment: no per-kernel HIP events in the timed region (roofline fields become null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=16)
     ap.add_argument("--cpu-iters", type=int, default=6)
@@ -125,7 +127,8 @@ def main():
     mu_tab, sig_tab = synthetic.param_table(n, total_iters, seed=77 + rank)
 
     bf16 = args.convs == "bf16"
-    eng = PnPEngine(n, h, w, device=local_rank, profile=True, bf16_convs=bf16)
+    eng = PnPEngine(n, h, w, device=local_rank, profile=not args.no_kernel_events, bf16_convs=bf16,
+                    profile_layers=args.dump_layers is not None)      # the per-layer table costs an event pair per launch
     eng.load_weights(sd_np)
     x0 = torch.view_as_complex(torch.from_numpy(data["x0"])).to(dev)
     y0 = torch.view_as_complex(torch.from_numpy(data["y0"])).to(dev)
@@ -199,6 +202,9 @@ def main():
                 "traffic": conv_traffic_bytes(n, h, w),
                 "traffic_note": "HBM bytes per step of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 "
                                 "correction + WRITE_SIZE, separate passes; profiles/r01_traffic.json), not measured in this run",
+                "timing": "one HIP event pair on the launch stream around the run of consecutive conv3x3 launches of each step "
+                          "(26 launches, nothing else in between), summed over the timed region; --dump-layers switches to a pair "
+                          "per launch (costs ~0.2 ms per step)",
                 "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / kernel time; Winograd layers issue 16/36 of "
                         "those multiplies, so frac can exceed 1.  executed = MFMA FLOPs actually issued / kernel time.",
                 "executed": round(executed, 3) if executed else None,

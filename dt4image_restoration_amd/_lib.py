@@ -12,6 +12,7 @@ PNP_FLAG_PROFILE = 1
 PNP_FLAG_NO_DENOISER = 2
 PNP_FLAG_KEEP_STAGES = 4
 PNP_FLAG_BF16_CONVS = 8
+PNP_FLAG_PROFILE_LAYERS = 16
 PROFILE_CLASSES = 6
 PROFILE_CLASS_NAMES = ("conv3x3_mfma", "conv_first", "conv_last", "fft_rows", "fft_cols_prox", "other")
 N_LAYERS = 28

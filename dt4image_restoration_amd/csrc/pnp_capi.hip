@@ -38,6 +38,7 @@ constexpr size_t kNParams = 11773857;
 struct EventPair {
     hipEvent_t a, b;
     int cls, layer;
+    int count;      // kernel launches between the two events (a run of same-class kernels shares one pair)
 };
 
 struct LevelBufs {
@@ -82,12 +83,17 @@ namespace {
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// One HIP event pair around a kernel launch - or, with `defer_end`, around a RUN of same-class launches that follow each
+// other on the stream (the 26 conv3x3 launches of a denoiser forward): `count` launches, closed by end().  Event records
+// cost ~3 us of stream time each, so the default profile mode brackets the conv run once; PNP_FLAG_PROFILE_LAYERS keeps
+// a pair per launch for the per-layer table.
 struct Prof {
     pnp_engine* e;
     hipStream_t s;
     EventPair* ep = nullptr;
-    Prof(pnp_engine* e_, hipStream_t s_, int cls, int layer) : e(e_), s(s_) {
-        if (!(e->cfg.flags & PNP_FLAG_PROFILE)) return;
+    bool deferred = false;
+    Prof(pnp_engine* e_, hipStream_t s_, int cls, int layer, bool active = true, bool defer_end = false) : e(e_), s(s_), deferred(defer_end) {
+        if (!active || !(e->cfg.flags & (PNP_FLAG_PROFILE | PNP_FLAG_PROFILE_LAYERS))) return;
         if (e->ev_used == e->events.size()) {
             EventPair p{};
             if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
@@ -96,10 +102,15 @@ struct Prof {
         ep = &e->events[e->ev_used++];
         ep->cls = cls;
         ep->layer = layer;
+        ep->count = 1;
         (void)hipEventRecord(ep->a, s);
     }
+    void end(int count) {
+        if (ep) { ep->count = count; (void)hipEventRecord(ep->b, s); ep = nullptr; }
+    }
     ~Prof() {
-        if (ep) (void)hipEventRecord(ep->b, s);
+        if (ep && !deferred) (void)hipEventRecord(ep->b, s);
+        else if (ep) { ep->count = 0; (void)hipEventRecord(ep->b, s); }     // a run left early (error path)
     }
 };
 
@@ -124,6 +135,9 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         Prof p(e, s, 1, 0);
         HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
     }
+    const bool per_layer = (e->cfg.flags & PNP_FLAG_PROFILE_LAYERS) != 0;
+    Prof run(e, s, 0, -1, !per_layer, true);              // one event pair around the whole conv3x3 run
+    int run_launches = 0;
     auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl, float* pooled = nullptr,
                     bool src_is_pooled = false) -> int {
         const LayerSpec& L = kLayers[li];
@@ -138,7 +152,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
             a.rw = a.W > 1 ? (float)(ws - 1) / (float)(a.W - 1) : 0.f;
         }
         const int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
-        Prof p(e, s, 0, li);
+        Prof p(e, s, 0, li, per_layer);
+        ++run_launches;
         if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, src_mode, s));
         else HIP_TRY(launch_conv3x3(a, src_mode, s));
         return PNP_OK;
@@ -174,11 +189,16 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
-        Prof p(e, s, 0, 26);
-        if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, SRC_PLAIN, s));
-        else HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
+        {
+            Prof p(e, s, 0, 26, per_layer);
+            ++run_launches;
+            if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, SRC_PLAIN, s));
+            else HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
+        }
+        run.end(run_launches);
     } else {
         if ((rc = conv(26, e->lv[0].q, nullptr, e->lv[0].p, 0))) return rc;
+        run.end(run_launches);
         Prof p(e, s, 2, 27);
         HIP_TRY(launch_conv_last(e->lv[0].p, ximg, z, u, tact, e->d_wpack[27], e->d_bias[27], out, N, H, W, s));
     }
@@ -472,7 +492,7 @@ int pnp_profile_collect(pnp_handle e, double* total_ms, int64_t* launches) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->events[i].a, e->events[i].b));
         const EventPair& p = e->events[i];
-        e->cls_ms[p.cls] += ms; e->cls_n[p.cls] += 1;
+        e->cls_ms[p.cls] += ms; e->cls_n[p.cls] += p.count;
         if (p.layer >= 0) { e->layer_ms[p.layer] += ms; e->layer_n[p.layer] += 1; }
     }
     e->ev_used = 0;

@@ -26,7 +26,7 @@ class PnPEngine:
     """Owns the workspace for N slices of H x W on one GPU.  Not thread-safe; one per process/GPU."""
 
     def __init__(self, n: int, h: int, w: int, device: Optional[int] = None, profile: bool = False,
-                 denoiser: bool = True, keep_stages: bool = False, bf16_convs: bool = False):
+                 denoiser: bool = True, keep_stages: bool = False, bf16_convs: bool = False, profile_layers: bool = False):
         if not torch.cuda.is_available():
             raise _lib.PnPError("PnPEngine needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load()
@@ -34,12 +34,13 @@ class PnPEngine:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         flags = ((_lib.PNP_FLAG_PROFILE if profile else 0) | (0 if denoiser else _lib.PNP_FLAG_NO_DENOISER)
-                 | (_lib.PNP_FLAG_KEEP_STAGES if keep_stages else 0) | (_lib.PNP_FLAG_BF16_CONVS if bf16_convs else 0))
+                 | (_lib.PNP_FLAG_KEEP_STAGES if keep_stages else 0) | (_lib.PNP_FLAG_BF16_CONVS if bf16_convs else 0)
+                 | (_lib.PNP_FLAG_PROFILE_LAYERS if profile_layers else 0))
         cfg = _lib.pnp_config(self.n, self.h, self.w, self.device_index, flags)
         hnd = C.c_void_p()
         _lib.check(self.lib.pnp_create(C.byref(cfg), C.byref(hnd)), "pnp_create")
         self._h = hnd
-        self.profile = profile
+        self.profile = profile or profile_layers
         self.bf16_convs = bool(bf16_convs)
 
     def close(self):

@@ -48,7 +48,9 @@ typedef struct {
     int32_t flags;    /* PNP_FLAG_* */
 } pnp_config;
 
-#define PNP_FLAG_PROFILE 1       /* record a HIP event pair around every kernel launch (pnp_profile_*) */
+#define PNP_FLAG_PROFILE 1       /* kernel-class timing with HIP events on the launch stream (pnp_profile_collect): one pair
+                                    around the run of conv3x3 launches of a denoiser forward, one per other kernel */
+#define PNP_FLAG_PROFILE_LAYERS 16  /* an event pair around EVERY launch (adds pnp_profile_layers; ~0.2 ms per step) */
 #define PNP_FLAG_NO_DENOISER 2   /* k-space-only handle (pnp_fft2c / pnp_psnr): no activation planes */
 #define PNP_FLAG_KEEP_STAGES 4   /* keep every U-Net stage output in memory for pnp_unet_read_stage (disables the
                                     fusion of the last 1x1 layer into the preceding conv's epilogue) */
@@ -147,7 +149,7 @@ int pnp_unet_read_stage(pnp_handle h, int which, float* dst, int* c, int* hh, in
 #define PNP_PROFILE_CLASSES 6
 int pnp_profile_reset(pnp_handle h);
 int pnp_profile_collect(pnp_handle h, double* total_ms, int64_t* launches);
-/* per-conv-layer totals (28 entries, execution order) from the same events */
+/* per-conv-layer totals (28 entries, execution order); handles created with PNP_FLAG_PROFILE_LAYERS only */
 int pnp_profile_layers(pnp_handle h, double* layer_ms, int64_t* layer_launches);
 
 /* Which kernel each of the 28 conv layers runs on for this handle's problem size (valid after

@@ -5,8 +5,10 @@
 set -e -o pipefail
 TAG=${1:-r01}; N=${2:-1}
 R=$(pwd); G=$R/gpurun_out; mkdir -p "$G"
-python3 bench.py --dump-layers "$G/layers_$TAG.json" > "$G/bench_$TAG.json" 2> "$G/bench_$TAG.err"
+python3 bench.py > "$G/bench_$TAG.json" 2> "$G/bench_$TAG.err"
 echo "bench done: $(cut -c1-120 "$G/bench_$TAG.json")"
+python3 bench.py --no-cpu-baseline --dump-layers "$G/layers_$TAG.json" > "$G/bench_layers_$TAG.json" 2>> "$G/bench_$TAG.err"   # an event pair per launch
+echo "layer table done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$G/prof_$TAG" -o runc -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$G/bench_prof_$TAG.json" 2> "$G/prof_$TAG.err"
 echo "stats done"
