@@ -229,3 +229,34 @@ def test_bf16_convs_trajectory_psnr_offsets(sd_np):
         p = e.psnr(x, gt).cpu()
         assert float((p - O.psnr(sb["x"], sb["gt"]).reshape(-1)).abs().max()) < 0.01
         assert float((p - O.psnr(sf["x"], sf["gt"]).reshape(-1)).abs().max()) < 0.02
+
+
+# ---- shape sweep: every tile-width variant, ragged tile grids, every batch remainder ---------------------------------------
+_SWEEP = [(1, 16, 48), (5, 32, 16), (2, 80, 48), (3, 96, 112), (1, 144, 64), (4, 16, 16), (2, 64, 176), (1, 208, 32)]
+
+
+@pytest.mark.parametrize("mode", ["default", "winograd", "direct", "bf16"])
+@pytest.mark.parametrize("n,h,w", _SWEEP)
+def test_denoiser_shape_sweep(sd_np, n, h, w, mode, monkeypatch):
+    """The U-Net needs H, W multiples of 16 only (noise.py:49-53 pad is then a no-op); sizes that are NOT multiples of the
+    kernels' 32-/16-/8-wide tiles exercise partial tiles, odd tile grids and the low-res upsample staging at image borders,
+    on each kernel family: plan defaults, Winograd forced on every eligible layer, direct f32 only, bf16 operands."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    if mode == "winograd":
+        monkeypatch.setenv("PNP_WINO_MIN_BLOCKS", "1")
+    if mode == "direct":
+        monkeypatch.setenv("PNP_NO_WINOGRAD", "1")
+    e = PnPEngine(n, h, w, bf16_convs=(mode == "bf16"))
+    e.load_weights(sd_np)
+    algos = e.conv_algorithms()[1:27]
+    if mode == "winograd":
+        assert any(v == 1 for v in algos)
+    if mode in ("direct", "bf16"):
+        assert all(v == 0 for v in algos)
+    sd = O.torch_weights(sd_np)
+    x = (torch.from_numpy(synthetic.hash_uniform(21, h * 1000 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
+    sigma = torch.linspace(3, 60, n) / 255.0
+    got = e.denoise(x.cuda(), sigma.cuda()).cpu()
+    ref = O.denoise(sd, x, sigma, bf16_operands=(mode == "bf16"))
+    # FLOAT TOLERANCE: f32 summation order (1e-5); bf16 operands: rounding flips reach the output at ~1e-3 (see above)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-3 if mode == "bf16" else 1e-5)
