@@ -82,10 +82,119 @@ __device__ float2* fft_lines(float2* src, float2* dst, const float2* tw, int L, 
     return src;
 }
 
+// Compile-time sizes (L = 128 / 256 / 512, the sizes of BASELINE's configs): every pass is fully unrolled and reads all of a
+// thread's butterflies (IT x 4 points + twiddles) before it computes, so LDS latency is paid once per pass instead of once
+// per butterfly.  256 threads; LINES * L / 4 must be a multiple of 256.
+template <bool INV, int L, int LINES, int LSTR, int NS, bool INPLACE = false>
+__device__ __forceinline__ void fft_pass4(const float2* src, float2* dst, const float2* __restrict__ tw) {
+    constexpr int per4 = L / 4, IT = LINES * per4 / 256, tstep = L / (4 * NS);
+    static_assert((LINES * per4) % 256 == 0, "whole batches of 256 butterflies");
+    const int tid = threadIdx.x;
+    float2 v[IT][4], w[IT][3];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        const int line = idx / per4, j = idx % per4;
+        const float2* sp = src + line * LSTR + j;
+        v[it][0] = sp[0]; v[it][1] = sp[per4]; v[it][2] = sp[2 * per4]; v[it][3] = sp[3 * per4];
+        if (NS > 1) {
+            const int k = j & (NS - 1);
+            w[it][0] = tw[k * tstep]; w[it][1] = tw[2 * k * tstep]; w[it][2] = tw[3 * k * tstep];
+        }
+    }
+    if (INPLACE) __syncthreads();                          // src == dst: every read of the pass before any write
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        const int line = idx / per4, j = idx % per4;
+        const int k = j & (NS - 1);
+        float2 v0 = v[it][0], v1 = v[it][1], v2 = v[it][2], v3 = v[it][3];
+        if (NS > 1) {
+            float2 w1 = w[it][0], w2 = w[it][1], w3 = w[it][2];
+            if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+        }
+        const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3);
+        const float2 d = csub(v1, v3);
+        const float2 t3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+/- i) * d
+        float2* dp = dst + line * LSTR + ((j - k) << 2) + k;
+        dp[0] = cadd(t0, t2);
+        dp[NS] = cadd(t1, t3);
+        dp[2 * NS] = csub(t0, t2);
+        dp[3 * NS] = csub(t1, t3);
+    }
+}
+
+template <bool INV, int L, int LINES, int LSTR, int NS, bool INPLACE = false>
+__device__ __forceinline__ void fft_pass2(const float2* src, float2* dst, const float2* __restrict__ tw) {
+    constexpr int per2 = L / 2, IT = LINES * per2 / 256;
+    static_assert((LINES * per2) % 256 == 0 && NS * 2 == L, "radix-2 tail");
+    const int tid = threadIdx.x;
+    float2 v[IT][2], w[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        const int line = idx / per2, j = idx % per2;
+        const float2* sp = src + line * LSTR + j;
+        v[it][0] = sp[0]; v[it][1] = sp[per2];
+        w[it] = tw[j & (NS - 1)];                              // k * (L / (2 NS)) = k
+    }
+    if (INPLACE) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        const int line = idx / per2, j = idx % per2;
+        const int k = j & (NS - 1);
+        float2 ww = w[it];
+        if (INV) ww.y = -ww.y;
+        const float2 v1 = cmul(v[it][1], ww);
+        float2* dp = dst + line * LSTR + ((j - k) << 1) + k;
+        dp[0] = cadd(v[it][0], v1);
+        dp[NS] = csub(v[it][0], v1);
+    }
+}
+
+// Same contract as fft_lines (caller has synchronised the loads; returns the buffer holding the synchronised result).
+template <bool INV, int L, int LINES, int LSTR>
+__device__ __forceinline__ float2* fft_lines_ct(float2* src, float2* dst, const float2* tw) {
+#define PNP_FFT_STEP(NS_)                                                                              \
+    if constexpr (NS_ * 4 <= L) {                                                                      \
+        fft_pass4<INV, L, LINES, LSTR, NS_>(src, dst, tw);                                             \
+        __syncthreads();                                                                               \
+        float2* t_ = src; src = dst; dst = t_;                                                         \
+    }
+    PNP_FFT_STEP(1) PNP_FFT_STEP(4) PNP_FFT_STEP(16) PNP_FFT_STEP(64) PNP_FFT_STEP(256)
+#undef PNP_FFT_STEP
+    constexpr int NS4 = L >= 1024 ? 1024 : (L >= 256 ? 256 : (L >= 64 ? 64 : (L >= 16 ? 16 : (L >= 4 ? 4 : 1))));
+    if constexpr (NS4 < L) {
+        fft_pass2<INV, L, LINES, LSTR, NS4>(src, dst, tw);
+        __syncthreads();
+        float2* t_ = src; src = dst; dst = t_;
+    }
+    return src;
+}
+
+// In place in ONE buffer (half the LDS, twice the barriers): the register batch of a pass is the second buffer.
+template <bool INV, int L, int LINES, int LSTR>
+__device__ __forceinline__ void fft_lines_inplace(float2* buf, const float2* tw) {
+#define PNP_FFT_STEP(NS_)                                                                              \
+    if constexpr (NS_ * 4 <= L) {                                                                      \
+        fft_pass4<INV, L, LINES, LSTR, NS_, true>(buf, buf, tw);                                       \
+        __syncthreads();                                                                               \
+    }
+    PNP_FFT_STEP(1) PNP_FFT_STEP(4) PNP_FFT_STEP(16) PNP_FFT_STEP(64) PNP_FFT_STEP(256)
+#undef PNP_FFT_STEP
+    constexpr int NS4 = L >= 1024 ? 1024 : (L >= 256 ? 256 : (L >= 64 ? 64 : (L >= 16 ? 16 : (L >= 4 ? 4 : 1))));
+    if constexpr (NS4 < L) {
+        fft_pass2<INV, L, LINES, LSTR, NS4, true>(buf, buf, tw);
+        __syncthreads();
+    }
+}
+
 static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in the row passes
 
 // MODE 0 generic (in -> out, index shifts), 1 ADMM forward (x + u -> work), 2 ADMM inverse (work -> z, u)
-template <int MODE>
+template <int MODE, int LC>
 __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2* out,
                                                        const float* __restrict__ x, float2* __restrict__ u,
                                                        const float2* __restrict__ twg, const float* __restrict__ tact,
@@ -124,7 +233,14 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     }
     __syncthreads();
     const bool inv = (MODE == 2) || (MODE == 0 && inverse);
-    float2* res = inv ? fft_lines<true>(buf0, buf1, tw, W, rpb, W) : fft_lines<false>(buf0, buf1, tw, W, rpb, W);
+    float2* res;
+    if constexpr (LC > 0) {                                // W == LC, rpb == ROW_ELEMS / LC (checked by the launcher)
+        if constexpr (MODE == 2) res = fft_lines_ct<true, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
+        else if constexpr (MODE == 1) res = fft_lines_ct<false, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
+        else res = inv ? fft_lines_ct<true, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw) : fft_lines_ct<false, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
+    } else {
+        res = inv ? fft_lines<true>(buf0, buf1, tw, W, rpb, W) : fft_lines<false>(buf0, buf1, tw, W, rpb, W);
+    }
     const float sc = rsqrtf((float)W);
     for (int e0 = threadIdx.x; e0 < tot; e0 += NB * 256) {
         float2 uu[NB];
@@ -156,7 +272,7 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
 
 // Column pass over CW adjacent columns of one slice.  MODE 0 generic in-place transform with row-index
 // shifts; MODE 1 forward -> prox -> inverse (ADMM).
-template <int MODE>
+template <int MODE, int LC>
 __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data, const float2* __restrict__ twg,
                                                        const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
                                                        int mask_n, const float* __restrict__ mu,
@@ -166,7 +282,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
     const int lstr = H + 1;
     float2* buf0 = smem;
     float2* buf1 = smem + cw * lstr;
-    float2* tw = smem + 2 * cw * lstr;
+    float2* tw = smem + ((MODE == 1 && LC > 0) ? 1 : 2) * cw * lstr;   // the unrolled ADMM variant works in place in buf0
     const int strips = W / cw;
     const int n = blockIdx.x / strips;
     const int x0 = (blockIdx.x % strips) * cw;
@@ -196,6 +312,47 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
         for (int e = threadIdx.x; e < tot; e += 256) {
             const int r = e >> lcw, c = e & (cw - 1);
             float2 v = res[c * lstr + (r ^ shift_out)];
+            v.x *= sc; v.y *= sc;
+            img[(size_t)r * W + x0 + c] = v;
+        }
+    } else if constexpr (LC > 0) {
+        // H == LC, cw == CWC (checked by the launcher): the k-space constants of this strip are fetched BEFORE the forward
+        // transform and sit in registers under it; all passes unrolled.
+        constexpr int CWC = LC <= 256 ? 16 : (LC <= 512 ? 8 : 4), LS = LC + 1, PER = CWC * LC / 256;
+        const float m = mu[n];
+        const float inv1m = 1.f + m;
+        const float2* y0n = y0s + (size_t)n * H * W;
+        const uint8_t* mk = masks + (mask_n > 1 ? (size_t)n * H * W : 0);
+        float2 yy[PER];
+        uint8_t mm[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x + k * 256;
+            const size_t g = (size_t)(e / CWC) * W + x0 + (e % CWC);
+            mm[k] = mk[g];
+            yy[k] = y0n[g];
+        }
+        fft_lines_inplace<false, LC, CWC, LS>(buf0, tw);
+        float2* const res = buf0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x + k * 256;
+            const int r = e / CWC, c = e % CWC;
+            float2 v = res[c * LS + r];
+            v.x *= sc; v.y *= sc;                           // now the orthonormal FFT2 of x + u
+            if (mm[k]) {                                    // sampled k-space bin: closed-form solve
+                v.x = (m * v.x + yy[k].x) / inv1m;
+                v.y = (m * v.y + yy[k].y) / inv1m;
+            }
+            res[c * LS + r] = v;
+        }
+        __syncthreads();
+        fft_lines_inplace<true, LC, CWC, LS>(res, tw);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x + k * 256;
+            const int r = e / CWC, c = e % CWC;
+            float2 v = res[c * LS + r];
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
         }
@@ -248,9 +405,15 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
 static hipError_t raise_lds_cap() {
     static bool done = false;
     if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)fft_cols_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)fft_cols_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) return e;
     done = true;
     return hipSuccess;
@@ -272,7 +435,7 @@ hipError_t launch_fft_rows_generic(const float2* in, float2* out, const float2* 
                                    int shift_in, int shift_out, hipStream_t s) {
     const int rpb = rows_per_block(H, W);
     const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
-    hipLaunchKernelGGL(fft_rows_kernel<0>, dim3(batch * (H / rpb)), dim3(256), lds, s, in, out, nullptr, nullptr, tw,
+    hipLaunchKernelGGL((fft_rows_kernel<0, 0>), dim3(batch * (H / rpb)), dim3(256), lds, s, in, out, nullptr, nullptr, tw,
                        nullptr, H, W, rpb, inverse, shift_in, shift_out);
     return hipGetLastError();
 }
@@ -281,7 +444,7 @@ hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, in
     const int cw = cols_per_block(H, W);
     const size_t lds = (size_t)(2 * cw * (H + 1) + H) * sizeof(float2);
     if (hipError_t e = raise_lds_cap()) return e;
-    hipLaunchKernelGGL(fft_cols_kernel<0>, dim3(batch * (W / cw)), dim3(256), lds, s, data, tw, nullptr, nullptr, 1,
+    hipLaunchKernelGGL((fft_cols_kernel<0, 0>), dim3(batch * (W / cw)), dim3(256), lds, s, data, tw, nullptr, nullptr, 1,
                        nullptr, nullptr, H, W, cw, inverse, shift_in, shift_out);
     return hipGetLastError();
 }
@@ -289,25 +452,47 @@ hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* wor
                                     int N, int H, int W, hipStream_t s) {
     const int rpb = rows_per_block(H, W);
     const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
-    hipLaunchKernelGGL(fft_rows_kernel<1>, dim3(N * (H / rpb)), dim3(256), lds, s, nullptr, work, x,
-                       const_cast<float2*>(u), tw, tact, H, W, rpb, 0, 0, 0);
+#define PNP_ROWS_FWD(LC_)                                                                                      \
+    hipLaunchKernelGGL((fft_rows_kernel<1, LC_>), dim3(N * (H / rpb)), dim3(256), lds, s, nullptr, work, x,      \
+                       const_cast<float2*>(u), tw, tact, H, W, rpb, 0, 0, 0)
+    const bool ct = rpb == ROW_ELEMS / W;                  // the unrolled variants assume a full ROW_ELEMS batch
+    if (ct && W == 128) PNP_ROWS_FWD(128);
+    else if (ct && W == 256) PNP_ROWS_FWD(256);
+    else if (ct && W == 512) PNP_ROWS_FWD(512);
+    else PNP_ROWS_FWD(0);
+#undef PNP_ROWS_FWD
     return hipGetLastError();
 }
 hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0s, const uint8_t* masks, int mask_n,
                                 const float* mu, const float* tact, int N, int H, int W, hipStream_t s) {
     const int cw = cols_per_block(H, W);
-    const size_t lds = (size_t)(2 * cw * (H + 1) + H) * sizeof(float2);
+    size_t lds = (size_t)(2 * cw * (H + 1) + H) * sizeof(float2);
     if (hipError_t e = raise_lds_cap()) return e;
-    hipLaunchKernelGGL(fft_cols_kernel<1>, dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu,
-                       tact, H, W, cw, 0, 0, 0);
+#define PNP_COLS_PROX(LC_)                                                                                    \
+    hipLaunchKernelGGL((fft_cols_kernel<1, LC_>), dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu, \
+                       tact, H, W, cw, 0, 0, 0)
+    const bool ct = cw == (H <= 256 ? 16 : (H <= 512 ? 8 : 4)) && (H == 128 || H == 256 || H == 512);   // W >= one full strip
+    if (ct) lds = (size_t)(cw * (H + 1) + H) * sizeof(float2);      // in place: one strip buffer
+    if (ct && H == 128) PNP_COLS_PROX(128);
+    else if (ct && H == 256) PNP_COLS_PROX(256);
+    else if (ct && H == 512) PNP_COLS_PROX(512);
+    else PNP_COLS_PROX(0);
+#undef PNP_COLS_PROX
     return hipGetLastError();
 }
 hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
                                     const float* tact, int N, int H, int W, hipStream_t s) {
     const int rpb = rows_per_block(H, W);
     const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
-    hipLaunchKernelGGL(fft_rows_kernel<2>, dim3(N * (H / rpb)), dim3(256), lds, s, work, z, x, u, tw, tact, H, W, rpb,
-                       1, 0, 0);
+#define PNP_ROWS_INV(LC_)                                                                                      \
+    hipLaunchKernelGGL((fft_rows_kernel<2, LC_>), dim3(N * (H / rpb)), dim3(256), lds, s, work, z, x, u, tw, tact, H, W, rpb, \
+                       1, 0, 0)
+    const bool ct = rpb == ROW_ELEMS / W;
+    if (ct && W == 128) PNP_ROWS_INV(128);
+    else if (ct && W == 256) PNP_ROWS_INV(256);
+    else if (ct && W == 512) PNP_ROWS_INV(512);
+    else PNP_ROWS_INV(0);
+#undef PNP_ROWS_INV
     return hipGetLastError();
 }
 
