@@ -106,6 +106,12 @@ def main():
     ap.add_argument("--dump-layers", default=None, help="write the per-layer kernel time table (JSON) here")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that print banners to fd 1 (RCCL prints its version block
+    # when the first communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +263,8 @@ def main():
             cb.pop("slice_iters_per_s")
             out["cpu_baseline"] = cb
             out["psnr_delta_vs_oracle_db"] = float(dpsnr)          # the oracle here is always the f32 reference arithmetic
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
