@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.pnp_version()
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/pnpadmm.h compiles as strict C99 and a C program links against the library and
+    calls it (argument validation only - no GPU needed)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "pnpadmm.h"\n'
+        "int main(void) {\n"
+        "    pnp_handle h = 0;\n"
+        "    pnp_config bad = {0, 128, 128, 0, 0};\n"
+        "    if (pnp_create(&bad, &h) == PNP_OK) return 1;          /* n = 0 must be rejected before any HIP call */\n"
+        "    if (strlen(pnp_last_error()) == 0) return 2;\n"
+        "    if (pnp_step(0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == PNP_OK) return 3;   /* null handle */\n"
+        "    if (pnp_snapshot_bytes(0) != 0) return 4;\n"
+        '    printf("%s\\n", pnp_version());\n'
+        "    return 0;\n}\n")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe), "-L", libdir, "-lpnpadmm", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
 def test_create_rejects_bad_config_without_touching_a_gpu():
     import ctypes as C
     lib = _lib.load()
