@@ -40,14 +40,25 @@ def mfma_conv_flops(n, h, w):
                    for l in unet_spec.UNET_LAYERS[1:27])
 
 
-def conv_traffic_bytes(n, h, w):
-    """PMC-measured HBM traffic of the conv kernels per step (profiles/r01_traffic.json, configs[1] only)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if (n, h, w) != (64, 256, 256) or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        t = json.load(f)
-    return int(t["conv_kernels_fetch_bytes_per_step"] + t["conv_kernels_write_bytes_per_step"])
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first
+
+
+def pmc_traffic(n, h, w, which):
+    """PMC-measured HBM bytes per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 passes of this
+    same command, folded by tools/refresh_profiles.py into profiles/rNN_traffic.json; configs[1] only).
+    which: "conv" (the 26 conv3x3 launches) or "fft" (the three data-fidelity launches).  Returns (bytes, file) or (None, None)."""
+    if (n, h, w) != (64, 256, 256):
+        return None, None
+    for name in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            t = json.load(f)
+        kf, kw = f"{which}_kernels_fetch_bytes_per_step", f"{which}_kernels_write_bytes_per_step"
+        if kf in t and kw in t:
+            return int(t[kf] + t[kw]), "profiles/" + name
+    return None, None
 
 
 def host_cores():
@@ -93,6 +104,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=10,
+                    help="repetitions of the [reset, W warm-up steps, K timed steps] episode; the line reports the MEDIAN "
+                         "repetition (each one is exactly K steps between barrier + synchronize brackets, max over ranks)")
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--convs", choices=("f32", "bf16"), default="f32",
@@ -142,39 +156,53 @@ def main():
     gt = torch.from_numpy(data["gt"]).to(dev)
     mu_d = torch.from_numpy(mu_tab).to(dev).t().contiguous()       # [iters, n]
     sg_d = torch.from_numpy(sig_tab).to(dev).t().contiguous()
-    x, z, u = eng.reset(x0, y0, mask)
-    psnr0 = eng.psnr(x, gt)
-
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for t in range(args.warmup):
-        eng.step(x, z, u, mu_d[t], sg_d[t])
-    torch.cuda.synchronize()
-    eng.profile_reset()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total_iters):
-        eng.step(x, z, u, mu_d[t], sg_d[t])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_collect()
-    psnr1 = eng.psnr(x, gt)
+    def episode():
+        """reset (untimed), W warm-up steps (untimed), then EXACTLY K steps between barrier + synchronize brackets."""
+        x, z, u = eng.reset(x0, y0, mask)
+        p0 = eng.psnr(x, gt)
+        for t in range(args.warmup):
+            eng.step(x, z, u, mu_d[t], sg_d[t])
+        torch.cuda.synchronize()
+        eng.profile_reset()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, total_iters):
+            eng.step(x, z, u, mu_d[t], sg_d[t])
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        pr = eng.profile_collect()
+        el = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), pr, p0, eng.psnr(x, gt)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    psnr_gain = (psnr1 - psnr0).mean().reshape(1).double()
+    reps = max(1, args.reps)
+    times, profs = [], []
+    for _ in range(reps):
+        dt, pr, psnr0, psnr1 = episode()
+        times.append(dt)
+        profs.append(pr)
+    order = sorted(range(reps), key=lambda i: times[i])
+    med = order[(reps - 1) // 2]                 # the median repetition (lower median for an even count)
+    elapsed = times[med]
+    # kernel-time fields: averaged over ALL repetitions (every repetition brackets the same launches with the same events)
+    prof = {k: ({"ms": sum(p[k]["ms"] for p in profs) / reps, "launches": profs[0][k]["launches"]} if k != "layers"
+                else {"ms": [sum(p["layers"]["ms"][i] for p in profs) / reps for i in range(len(profs[0]["layers"]["ms"]))],
+                      "launches": profs[0]["layers"]["launches"]}) for k in profs[0]}
+
     if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
         # the path's only collective: gather the per-slice PSNR of every shard (SURVEY 8e)
         allp = [torch.empty_like(psnr1) for _ in range(world)]
         dist.all_gather(allp, psnr1)
         psnr_all = torch.cat(allp)
     else:
         psnr_all = psnr1
-    elapsed = float(el.item())
 
     if rank == 0:
         steps = args.steps
@@ -182,13 +210,17 @@ def main():
         conv_ms = prof["conv3x3_mfma"]["ms"]
         conv_launches = prof["conv3x3_mfma"]["launches"]
         flops_step = mfma_conv_flops(n, h, w)
-        achieved = flops_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+        algorithmic = flops_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         algos = eng.conv_algorithms()
         mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
-        # MFMA flops actually issued: a Winograd F(2x2,3x3) layer multiplies 16 instead of 36 times per 2x2 outputs
-        exec_step = n * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * (16.0 / 36.0 if algos[l.index] == 1 else 1.0)
+        # MFMA flops actually ISSUED: a Winograd F(2x2,3x3) layer multiplies 16 instead of 36 times per 2x2 outputs, an
+        # F(4x4,3x3) layer 36 instead of 144 per 4x4 outputs
+        ratio = {0: 1.0, 1: 16.0 / 36.0, 4: 36.0 / 144.0}
+        exec_step = n * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * ratio.get(algos[l.index], 1.0)
                             for l in unet_spec.UNET_LAYERS[1:27])
         executed = exec_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+        conv_traffic, conv_traffic_src = pmc_traffic(n, h, w, "conv")
+        ms_all = sorted(1e3 * t / steps for t in times)
         out = {
             "metric": "pnp_admm_iterations_per_sec", "value": round(value, 4), "unit": "batch-iterations/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
@@ -198,24 +230,32 @@ def main():
                                    f"U-Net denoiser{' (bf16 conv operands)' if bf16 else ''} + FFT prox, "
                                    f"seeded per-slice (mu, sigma) table, {args.accel:g}x radial mask", "slices_per_gpu": n,
                        "global_slices": n * world, "h": h, "w": w, "sharding": f"slices over {world} rank(s), no data-path collective"},
+            "repetitions": {"n": reps, "what": "each = reset + W untimed warm-up steps + K timed steps (barrier + synchronize on both "
+                                               "sides, max over ranks); value / ms_per_step are the MEDIAN repetition",
+                            "ms_per_step_median": round(ms_all[(reps - 1) // 2], 4), "ms_per_step_min": round(ms_all[0], 4),
+                            "ms_per_step_max": round(ms_all[-1], 4), "ms_per_step_all": [round(1e3 * t / steps, 4) for t in times]},
             "slice_iterations_per_sec": round(value * n, 2),
             "psnr_mean_db": round(float(psnr_all.mean()), 4),
             "roofline": {
                 "kernel": "conv3x3_winograd_kernel + conv3x3_mfma_kernel (26 launches/step: all denoiser conv3x3 layers "
-                          f"with Cin>=32; {sum(1 for v in algos if v == 1)} on Winograd F(2x2,3x3), {sum(1 for v in algos if v == 0)} direct)",
-                "bound": "mfma", "achieved": round(achieved, 3) if achieved else None, "peak": mfma_peak,
-                "unit": "TFLOP/s", "frac": round(achieved / mfma_peak, 4) if achieved else None,
-                "traffic": conv_traffic_bytes(n, h, w),
-                "traffic_note": "HBM bytes per step of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 "
-                                "correction + WRITE_SIZE, separate passes; profiles/r01_traffic.json), not measured in this run",
+                          f"with Cin>=32; {sum(1 for v in algos if v == 4)} on Winograd F(4x4,3x3), {sum(1 for v in algos if v == 1)} "
+                          f"on Winograd F(2x2,3x3), {sum(1 for v in algos if v == 0)} direct)",
+                "bound": "mfma", "achieved": round(executed, 3) if executed else None, "peak": mfma_peak,
+                "unit": "TFLOP/s", "frac": round(executed / mfma_peak, 4) if executed else None,
+                "traffic": conv_traffic, "traffic_source": conv_traffic_src,
+                "traffic_note": "HBM bytes per step of the same kernels from rocprofv3 PMC passes of this command (FETCH_SIZE x2 gfx950 "
+                                "correction + WRITE_SIZE, separate passes), not measured in this run",
                 "timing": "one HIP event pair on the launch stream around the run of consecutive conv3x3 launches of each step "
-                          "(26 launches, nothing else in between), summed over the timed region; --dump-layers switches to a pair "
-                          "per launch (costs ~0.2 ms per step)",
-                "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / kernel time; Winograd layers issue 16/36 of "
-                        "those multiplies, so frac can exceed 1.  executed = MFMA FLOPs actually issued / kernel time.",
-                "executed": round(executed, 3) if executed else None,
-                "executed_frac": round(executed / mfma_peak, 4) if executed else None,
-                "flops_per_step": flops_step, "kernel_ms_per_step": round(conv_ms / steps, 4),
+                          "(26 launches, nothing else in between), averaged over the timed steps of all repetitions; --dump-layers "
+                          "switches to a pair per launch (costs ~0.2 ms per step)",
+                "note": "achieved / frac = MFMA FLOPs actually ISSUED by these kernels / kernel time (a true pipe fraction, <= 1).  "
+                        "algorithmic_tflops = the direct-convolution FLOPs of the same layers (SURVEY 8d) / the same time: Winograd "
+                        "layers issue winograd_multiply_ratio of those multiplies, so it may exceed the f32 MFMA peak.",
+                "algorithmic_tflops": round(algorithmic, 3) if algorithmic else None,
+                "algorithmic_frac_of_direct_peak": round(algorithmic / mfma_peak, 4) if algorithmic else None,
+                "winograd_multiply_ratio": round(exec_step / flops_step, 4),
+                "flops_per_step": flops_step, "mfma_flops_issued_per_step": int(exec_step),
+                "kernel_ms_per_step": round(conv_ms / steps, 4),
                 "launches_per_step": conv_launches / steps,
                 "other_kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()
                                               if k not in ("layers", "conv3x3_mfma")},
@@ -229,7 +269,8 @@ def main():
             out["roofline_fft"] = {
                 "kernel": "fft_rows_kernel<1> + fft_cols_kernel<1> + fft_rows_kernel<2> (3 launches/step)", "bound": "hbm",
                 "achieved": round(alg / (fft_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, h, w, "fft")[0],
+                "traffic_source": pmc_traffic(n, h, w, "fft")[1],
                 "bytes_per_step": int(alg), "kernel_ms_per_step": round(fft_ms, 4),
                 "moved_gbs": round(moved / (fft_ms * 1e-3) / 1e9, 1),
                 "note": "achieved = algorithmic 37 B/px (x 4 + u 8 + y0 8 + mask 1 read, z 8 + u 8 written) / kernel time; the "

@@ -32,6 +32,7 @@ SIGNATURES = {
     "pnp_version": (C.c_char_p, []),
     "pnp_load_unet_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "pnp_reset": (C.c_int, [C.c_void_p, _fp, _fp, _u8p, C.c_int, _fp, _fp, _fp, _vp]),
+    "pnp_set_kspace": (C.c_int, [C.c_void_p, _fp, _u8p, C.c_int, _vp]),
     "pnp_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _u8p, _vp]),
     "pnp_denoise": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _vp]),
     "pnp_fft2c": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

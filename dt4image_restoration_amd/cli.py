@@ -78,8 +78,9 @@ def main(argv=None):
             mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
             n = mat["gt"].shape[0]
             rtg = torch.full((n,), D.normalised_rtg(args.rtg))
+            first = mat.get("x0_raw")               # datasets.py:162: the policy's first token is the UNclipped Re x0
             if args.mode == "eval":
-                r = ev.run(mat, rtg, torch.from_numpy(tokens))
+                r = ev.run(mat, rtg, torch.from_numpy(tokens), first_state=first)
                 out.append({"set": name, "n": n, "psnr": float(r.reward.mean()), "psnr_increment": float((r.reward - r.initial_reward).mean()),
                             "mean_stop_iteration": float(r.stop_time.float().mean())})
             else:
@@ -96,7 +97,8 @@ def main(argv=None):
             for name, batch, tokens in _batches(args, flex_target=target):
                 mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
                 n = mat["gt"].shape[0]
-                r = ev.run(mat, torch.full((n,), D.normalised_rtg(target, flex=True)), torch.from_numpy(tokens))
+                r = ev.run(mat, torch.full((n,), D.normalised_rtg(target, flex=True)), torch.from_numpy(tokens),
+                           first_state=mat.get("x0_raw"))
                 incs.append(float((r.reward - r.initial_reward).mean()))
             out.append({"rtg_target": target, "average_increment": float(np.mean(incs))})
             print(json.dumps(out[-1]), flush=True)

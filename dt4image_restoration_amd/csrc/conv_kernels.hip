@@ -21,6 +21,7 @@
 #include "pnp_internal.h"
 #include "conv_staging.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace pnp {
 
@@ -522,10 +523,9 @@ static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, 
     else return launch_cfg<TW, 4, 4, 2, 2, 32, false, false>(a, p, src_mode, s);
 }
 
-hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
+hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
     if (a0.Cin % 32 != 0 || a0.Cout % 32 != 0 || (a0.Cout > 64 && a0.Cout % 128 != 0)) return hipErrorInvalidValue;
     const bool bf16 = a0.bf16 != 0;
-    const ConvPlan p = conv3x3_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout, bf16);
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
@@ -551,14 +551,36 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int src_mode, hipStream_t s) {
 }
 
 // The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
-bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout, bool bf16) {   // also: can fuse the last layer
-    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout, bf16);
+bool conv3x3_pooled_output_ok(const ConvPlan& p) {   // also: can fuse the last layer
     return p.splitk == 1 && p.mt == 2 && p.nt == 1 && p.wm == 4;
 }
 
-size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout, bool bf16) {
-    const ConvPlan p = conv3x3_plan(N, H, W, Cin, Cout, bf16);
+size_t conv3x3_partial_floats(const ConvPlan& p, int N, int H, int W, int Cout) {
     return (p.mt == 2 && p.wn >= 2) ? (size_t)p.splitk * N * H * W * Cout : 0;
+}
+
+Tuning tuning_from_env() {
+    Tuning t;
+    if (const char* v = getenv("PNP_WINO_MIN_CIN")) t.wino_min_cin = atoi(v);
+    if (const char* v = getenv("PNP_WINO_MIN_BLOCKS")) t.wino_min_blocks = atol(v);
+    t.wino_big = getenv("PNP_WINO_BIG_GROUPS") != nullptr;
+    t.wino_small = getenv("PNP_WINO_SMALL_GROUPS") != nullptr;
+    t.no_wino = getenv("PNP_NO_WINOGRAD") != nullptr;
+    if (const char* v = getenv("PNP_WINO_F4_MIN_CIN")) t.f4_min_cin = atoi(v);
+    t.no_f4 = getenv("PNP_NO_WINO_F4") != nullptr;
+    return t;
+}
+
+hipError_t raise_lds_cap(const void* fn, int bytes, DeviceOnce& once) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (once.mask.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    once.mask.fetch_or(bit, std::memory_order_relaxed);
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------

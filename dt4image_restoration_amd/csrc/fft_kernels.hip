@@ -403,19 +403,11 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
 
 // The column pass needs up to ~74 KiB of dynamic LDS (H = 1024); raise the per-kernel cap once.
 static hipError_t raise_lds_cap() {
-    static bool done = false;
-    if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)fft_cols_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)fft_cols_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    done = true;
+    static DeviceOnce once[5];
+    const void* fns[5] = {(const void*)fft_cols_kernel<0, 0>, (const void*)fft_cols_kernel<1, 0>, (const void*)fft_cols_kernel<1, 128>,
+                          (const void*)fft_cols_kernel<1, 256>, (const void*)fft_cols_kernel<1, 512>};
+    for (int i = 0; i < 5; ++i)
+        if (hipError_t e = pnp::raise_lds_cap(fns[i], 80 * 1024, once[i]); e != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -505,10 +497,12 @@ __global__ void reset_kernel(const float2* __restrict__ x0, const float2* __rest
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / hw, p = i - n * hw;
         const int k1 = (int)(p / W), k2 = (int)(p - (size_t)k1 * W);
-        const float2 v = x0[i];
-        x[i] = v.x;
-        z[i] = v;
-        u[i] = make_float2(0.f, 0.f);
+        if (x0 != nullptr) {                                   // null: only the episode constants are rebuilt (pnp_set_kspace)
+            const float2 v = x0[i];
+            x[i] = v.x;
+            z[i] = v;
+            u[i] = make_float2(0.f, 0.f);
+        }
         const size_t ps = (size_t)(k1 ^ (H >> 1)) * W + (k2 ^ (W >> 1));      // S: index + N/2 mod N (N power of two)
         const float sg = ((k1 + k2) & 1) ? -1.f : 1.f;
         const float2 yy = y0[n * hw + ps];

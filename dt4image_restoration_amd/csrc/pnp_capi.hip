@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,29 @@ int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail(PNP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// No C++ exception may cross the C ABI: every entry point body runs inside this guard.
+#define PNP_API_BEGIN try {
+#define PNP_API_END(name)                                                                          \
+    } catch (const std::bad_alloc&) { return fail(PNP_ERR_NOMEM, name ": out of host memory");     \
+    } catch (const std::exception& ex_) { return fail(PNP_ERR_INTERNAL, name ": %s", ex_.what());  \
+    } catch (...) { return fail(PNP_ERR_INTERNAL, name ": unknown C++ exception"); }
+
+// Entry points run on the handle's device whatever the caller's current device is, and leave the caller's current
+// device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define PNP_ON_DEVICE(e)                                                                                  \
+    DeviceGuard dev_guard_((e)->cfg.device);                                                              \
+    if (dev_guard_.err != hipSuccess) return fail(PNP_ERR_HIP, "hipSetDevice(%d): %s", (e)->cfg.device, hipGetErrorString(dev_guard_.err))
 
 constexpr size_t kNParams = 11773857;
 
@@ -60,6 +84,9 @@ struct pnp_engine {
     float* d_bias[N_LAYERS] = {};
     LevelBufs lv[5] = {};
     float* d_partial = nullptr;      // split-K workspace (small problems)
+    Tuning tune;                      // environment overrides, read once in pnp_create
+    WinoPlan wplan[N_LAYERS] = {};    // per-layer launch plans, fixed at pnp_create: the weight pack and every launch use
+    ConvPlan cplan[N_LAYERS] = {};    // the same plan
     bool wino[N_LAYERS] = {};         // layer runs on the Winograd kernel (weights packed for it)
     bool fuse_last = false;           // last 1x1 layer rides in the epilogue of up4.conv-2
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
@@ -154,8 +181,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         const int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;
-        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, src_mode, s));
-        else HIP_TRY(launch_conv3x3(a, src_mode, s));
+        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[li], src_mode, s));
+        else HIP_TRY(launch_conv3x3(a, e->cplan[li], src_mode, s));
         return PNP_OK;
     };
     int rc;
@@ -192,8 +219,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         {
             Prof p(e, s, 0, 26, per_layer);
             ++run_launches;
-            if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, SRC_PLAIN, s));
-            else HIP_TRY(launch_conv3x3(a, SRC_PLAIN, s));
+            if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[26], SRC_PLAIN, s));
+            else HIP_TRY(launch_conv3x3(a, e->cplan[26], SRC_PLAIN, s));
         }
         run.end(run_launches);
     } else {
@@ -228,22 +255,13 @@ int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float
 extern "C" {
 
 const char* pnp_last_error(void) { return g_err.c_str(); }
-const char* pnp_version(void) { return "pnpadmm 0.2 (gfx950, f32 MFMA; optional bf16-operand convs)"; }
+const char* pnp_version(void) { return "pnpadmm 0.3 (gfx950, f32 MFMA; optional bf16-operand convs)"; }
 
-int pnp_create(const pnp_config* cfg, pnp_handle* out) {
-    if (!cfg || !out) return fail(PNP_ERR_INVALID, "pnp_create: null argument");
-    if (cfg->n < 1 || cfg->h < 16 || cfg->w < 16 || cfg->h % 16 || cfg->w % 16)
-        return fail(PNP_ERR_INVALID, "pnp_create: need n >= 1 and h, w multiples of 16 (got n=%d h=%d w=%d)", cfg->n,
-                    cfg->h, cfg->w);
-    if (cfg->h > 1024 || cfg->w > 1024) return fail(PNP_ERR_INVALID, "pnp_create: h, w <= 1024");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (cfg->device < 0 || cfg->device >= ndev)
-        return fail(PNP_ERR_INVALID, "pnp_create: device %d of %d", cfg->device, ndev);
-    HIP_TRY(hipSetDevice(cfg->device));
-    pnp_engine* e = new pnp_engine();
+static int create_impl(const pnp_config* cfg, pnp_engine* e) {
     e->cfg = *cfg;
+    e->tune = tuning_from_env();
     const size_t N = cfg->n, H = cfg->h, W = cfg->w;
+    const bool bf16 = (cfg->flags & PNP_FLAG_BF16_CONVS) != 0;
     static const int chan[5] = {32, 64, 128, 256, 512};
     for (int k = 0; k < 5; ++k) {
         LevelBufs& L = e->lv[k];
@@ -255,39 +273,80 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
             const size_t bytes = (b == &L.pool) ? (k < 4 ? bytes_full / 4 : 0) : bytes_full;
             if (bytes == 0) continue;
             hipError_t er = hipMalloc((void**)b, bytes);
-            if (er != hipSuccess) { pnp_destroy(e); return fail(PNP_ERR_NOMEM, "activation planes: %s", hipGetErrorString(er)); }
+            if (er != hipSuccess) return fail(PNP_ERR_NOMEM, "activation planes: %s", hipGetErrorString(er));
             e->ws_bytes += bytes;
         }
     }
     if (!(cfg->flags & PNP_FLAG_NO_DENOISER)) {
+        // launch plans of the 26 conv3x3 layers: fixed here, used by the weight pack and by every launch
         size_t pf = 0;
         for (int li = 1; li < N_LAYERS - 1; ++li) {
             const LayerSpec& L = kLayers[li];
-            const size_t f = conv3x3_partial_floats(cfg->n, cfg->h >> L.level, cfg->w >> L.level, L.cin, L.cout,
-                                                    (cfg->flags & PNP_FLAG_BF16_CONVS) != 0);
+            const int lh = cfg->h >> L.level, lw = cfg->w >> L.level;
+            e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, e->tune);
+            e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16);
+            e->wino[li] = e->wplan[li].use && !bf16;
+            if (e->wino[li]) continue;
+            const size_t f = conv3x3_partial_floats(e->cplan[li], cfg->n, lh, lw, L.cout);
             if (f > pf) pf = f;
         }
         if (pf > 0) {
-            if (hipMalloc((void**)&e->d_partial, pf * sizeof(float)) != hipSuccess) { pnp_destroy(e); return fail(PNP_ERR_NOMEM, "split-K workspace"); }
+            if (hipMalloc((void**)&e->d_partial, pf * sizeof(float)) != hipSuccess) return fail(PNP_ERR_NOMEM, "split-K workspace");
             e->ws_bytes += pf * sizeof(float);
         }
+        // which stage outputs get a pooled copy: the producing conv (layers 2, 5, 8, 11) must run a kernel whose epilogue
+        // goes through LDS - the Winograd kernel, or the direct kernel's Cout = 32 configuration on a large problem
+        for (int k = 0; k < 4; ++k) {
+            const int li = 3 * k + 2;
+            const LayerSpec& L = kLayers[li];
+            const int lh = cfg->h >> L.level, lw = cfg->w >> L.level;
+            e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cplan[li]));
+        }
+        e->fuse_last = !(cfg->flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cplan[26]));
     }
     const size_t cbytes = N * H * W * sizeof(float2);
     if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||
-        hipMalloc((void**)&e->d_masks, N * H * W) != hipSuccess) {
-        pnp_destroy(e);
+        hipMalloc((void**)&e->d_masks, N * H * W) != hipSuccess)
         return fail(PNP_ERR_NOMEM, "k-space scratch");
-    }
     e->ws_bytes += 2 * cbytes + N * H * W;
     e->plan.h = cfg->h; e->plan.w = cfg->w;
     int rc;
-    if ((rc = make_twiddles(cfg->h, &e->plan.tw_h)) || (rc = make_twiddles(cfg->w, &e->plan.tw_w))) { pnp_destroy(e); return rc; }
-    *out = e;
+    if ((rc = make_twiddles(cfg->h, &e->plan.tw_h)) || (rc = make_twiddles(cfg->w, &e->plan.tw_w))) return rc;
     return PNP_OK;
 }
 
+int pnp_create(const pnp_config* cfg, pnp_handle* out) {
+    PNP_API_BEGIN
+    if (!cfg || !out) return fail(PNP_ERR_INVALID, "pnp_create: null argument");
+    *out = nullptr;
+    if (cfg->n < 1 || cfg->h < 16 || cfg->w < 16 || cfg->h % 16 || cfg->w % 16)
+        return fail(PNP_ERR_INVALID, "pnp_create: need n >= 1 and h, w multiples of 16 (got n=%d h=%d w=%d)", cfg->n,
+                    cfg->h, cfg->w);
+    if (cfg->h > 1024 || cfg->w > 1024) return fail(PNP_ERR_INVALID, "pnp_create: h, w <= 1024");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(PNP_ERR_INVALID, "pnp_create: device %d of %d", cfg->device, ndev);
+    pnp_engine* e = new (std::nothrow) pnp_engine();
+    if (!e) return fail(PNP_ERR_NOMEM, "pnp_create: out of host memory");
+    e->cfg = *cfg;
+    int rc;
+    {
+        DeviceGuard g(cfg->device);
+        if (g.err != hipSuccess) { delete e; return fail(PNP_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(g.err)); }
+        try { rc = create_impl(cfg, e); }
+        catch (...) { const std::string keep = g_err; pnp_destroy(e); g_err = keep; throw; }
+        if (rc != PNP_OK) { const std::string keep = g_err; pnp_destroy(e); g_err = keep; return rc; }
+    }
+    *out = e;
+    return PNP_OK;
+    PNP_API_END("pnp_create")
+}
+
 int pnp_destroy(pnp_handle e) {
+    PNP_API_BEGIN
     if (!e) return PNP_OK;
+    DeviceGuard g(e->cfg.device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
     for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); (void)hipFree(L.pool); }
@@ -296,84 +355,107 @@ int pnp_destroy(pnp_handle e) {
     for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete e;
     return PNP_OK;
+    PNP_API_END("pnp_destroy")
 }
 
 size_t pnp_workspace_bytes(pnp_handle e) { return e ? e->ws_bytes : 0; }
 
+// All-or-nothing: every layer is packed on the host and uploaded into NEW device buffers first; the handle's buffers are
+// replaced only when all 56 uploads succeeded, so a failure leaves the handle exactly as it was (an earlier successful
+// load stays usable, a never-loaded handle stays "weights not loaded").
 int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
+    PNP_API_BEGIN
     if (!e || !blob) return fail(PNP_ERR_INVALID, "pnp_load_unet_weights: null argument");
     if (n_floats != kNParams)
         return fail(PNP_ERR_INVALID, "pnp_load_unet_weights: expected %zu floats (56 tensors of UNet(2,1)), got %zu",
                     kNParams, n_floats);
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (e->cfg.flags & PNP_FLAG_NO_DENOISER) return fail(PNP_ERR_STATE, "pnp_load_unet_weights: handle created with PNP_FLAG_NO_DENOISER");
+    PNP_ON_DEVICE(e);
+    float* nw_pack[N_LAYERS] = {};
+    float* nw_bias[N_LAYERS] = {};
+    auto drop_new = [&]() { for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(nw_pack[i]); (void)hipFree(nw_bias[i]); } };
+    const bool bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0;
     size_t off = 0;
     std::vector<float> tmp;
-    for (int li = 0; li < N_LAYERS; ++li) {
-        const LayerSpec& L = kLayers[li];
-        const size_t nw = (size_t)L.cout * L.cin * L.ksize * L.ksize;
-        const float* w = blob + off;
-        const float* b = blob + off + nw;
-        off += nw + L.cout;
-        (void)hipFree(e->d_wpack[li]); (void)hipFree(e->d_bias[li]);
-        e->d_wpack[li] = e->d_bias[li] = nullptr;
-        size_t pf;
-        const float* src;
-        if (li == 0 || li == N_LAYERS - 1) {   // first (2->32, OIHW as is) and last (1x1) layers
-            pf = nw; src = w;
-        } else {
-            const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
-            const WinoPlan wp = winograd_plan(e->cfg.n, lh, lw, L.cin, L.cout);
-            const bool bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0;
-            e->wino[li] = wp.use && !bf16 && getenv("PNP_NO_WINOGRAD") == nullptr;
-            if (e->wino[li]) {
+    hipError_t er = hipSuccess;
+    try {
+        for (int li = 0; li < N_LAYERS && er == hipSuccess; ++li) {
+            const LayerSpec& L = kLayers[li];
+            const size_t nw = (size_t)L.cout * L.cin * L.ksize * L.ksize;
+            const float* w = blob + off;
+            const float* b = blob + off + nw;
+            off += nw + L.cout;
+            size_t pf;
+            const float* src;
+            if (li == 0 || li == N_LAYERS - 1) {   // first (2->32, OIHW as is) and last (1x1) layers
+                pf = nw; src = w;
+            } else if (e->wino[li]) {
                 pf = winograd_pack_floats(L.cin, L.cout);
-                tmp.resize(pf);
-                pack_winograd_weights(w, L.cin, L.cout, wp.ck, tmp.data());
+                tmp.assign(pf, 0.f);
+                pack_winograd_weights(w, L.cin, L.cout, e->wplan[li].ck, tmp.data());
+                src = tmp.data();
             } else {
                 pf = conv3x3_pack_floats(L.cin, L.cout);
-                tmp.resize(pf);
-                const int ck = conv3x3_plan(e->cfg.n, lh, lw, L.cin, L.cout, bf16).ck;
-                if (bf16) pack_conv3x3_weights_bf16(w, L.cin, L.cout, ck, tmp.data());
-                else pack_conv3x3_weights(w, L.cin, L.cout, ck, tmp.data());
+                tmp.assign(pf, 0.f);
+                if (bf16) pack_conv3x3_weights_bf16(w, L.cin, L.cout, e->cplan[li].ck, tmp.data());
+                else pack_conv3x3_weights(w, L.cin, L.cout, e->cplan[li].ck, tmp.data());
+                src = tmp.data();
             }
-            src = tmp.data();
+            if ((er = hipMalloc((void**)&nw_pack[li], pf * sizeof(float))) != hipSuccess) break;
+            if ((er = hipMemcpy(nw_pack[li], src, pf * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+            if ((er = hipMalloc((void**)&nw_bias[li], L.cout * sizeof(float))) != hipSuccess) break;
+            er = hipMemcpy(nw_bias[li], b, L.cout * sizeof(float), hipMemcpyHostToDevice);
         }
-        HIP_TRY(hipMalloc((void**)&e->d_wpack[li], pf * sizeof(float)));
-        HIP_TRY(hipMemcpy(e->d_wpack[li], src, pf * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&e->d_bias[li], L.cout * sizeof(float)));
-        HIP_TRY(hipMemcpy(e->d_bias[li], b, L.cout * sizeof(float), hipMemcpyHostToDevice));
+    } catch (...) { drop_new(); throw; }
+    if (er != hipSuccess) { drop_new(); return fail(PNP_ERR_HIP, "pnp_load_unet_weights: upload failed: %s (handle unchanged)", hipGetErrorString(er)); }
+    (void)hipDeviceSynchronize();                        // no launch still reads the buffers being replaced
+    for (int li = 0; li < N_LAYERS; ++li) {
+        (void)hipFree(e->d_wpack[li]); (void)hipFree(e->d_bias[li]);
+        e->d_wpack[li] = nw_pack[li]; e->d_bias[li] = nw_bias[li];
     }
-    // which stage outputs get a pooled copy: the producing conv (layers 2, 5, 8, 11) must run a kernel whose epilogue
-    // goes through LDS - the Winograd kernel, or the direct kernel's Cout = 32 configuration on a large problem
-    for (int k = 0; k < 4; ++k) {
-        const int li = 3 * k + 2;
-        const LayerSpec& L = kLayers[li];
-        const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
-        e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cfg.n, lh, lw, L.cin, L.cout, (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0));
-    }
-    e->fuse_last = !(e->cfg.flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cfg.n, e->cfg.h, e->cfg.w, kLayers[26].cin, kLayers[26].cout, (e->cfg.flags & PNP_FLAG_BF16_CONVS) != 0));
     e->weights_loaded = true;
     return PNP_OK;
+    PNP_API_END("pnp_load_unet_weights")
 }
 
 int pnp_reset(pnp_handle e, const float* x0, const float* y0, const uint8_t* mask, int mask_n, float* x, float* z,
               float* u, void* stream) {
+    PNP_API_BEGIN
     if (!e || !x0 || !y0 || !mask || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_reset: null argument");
     if (mask_n != 1 && mask_n != e->cfg.n) return fail(PNP_ERR_INVALID, "pnp_reset: mask_n must be 1 or n=%d", e->cfg.n);
     if (!is_pow2(e->cfg.h) || !is_pow2(e->cfg.w))
         return fail(PNP_ERR_INVALID, "pnp_reset: the k-space stage needs power-of-two h, w (got %dx%d)", e->cfg.h, e->cfg.w);
+    PNP_ON_DEVICE(e);
     e->mask_n = mask_n;
     HIP_TRY(launch_reset((const float2*)x0, (const float2*)y0, mask, mask_n, x, (float2*)z, (float2*)u, e->d_y0s,
                          e->d_masks, e->cfg.n, e->cfg.h, e->cfg.w, (hipStream_t)stream));
     e->reset_done = true;
     return PNP_OK;
+    PNP_API_END("pnp_reset")
+}
+
+int pnp_set_kspace(pnp_handle e, const float* y0, const uint8_t* mask, int mask_n, void* stream) {
+    PNP_API_BEGIN
+    if (!e || !y0 || !mask) return fail(PNP_ERR_INVALID, "pnp_set_kspace: null argument");
+    if (mask_n != 1 && mask_n != e->cfg.n) return fail(PNP_ERR_INVALID, "pnp_set_kspace: mask_n must be 1 or n=%d", e->cfg.n);
+    if (!is_pow2(e->cfg.h) || !is_pow2(e->cfg.w))
+        return fail(PNP_ERR_INVALID, "pnp_set_kspace: the k-space stage needs power-of-two h, w (got %dx%d)", e->cfg.h, e->cfg.w);
+    PNP_ON_DEVICE(e);
+    e->mask_n = mask_n;
+    HIP_TRY(launch_reset(nullptr, (const float2*)y0, mask, mask_n, nullptr, nullptr, nullptr, e->d_y0s, e->d_masks,
+                         e->cfg.n, e->cfg.h, e->cfg.w, (hipStream_t)stream));
+    e->reset_done = true;
+    return PNP_OK;
+    PNP_API_END("pnp_set_kspace")
 }
 
 int pnp_step(pnp_handle e, const float* mu, const float* sigma_d, const float* t_action, float* x, float* z, float* u,
              float* t_state, uint8_t* done, void* stream) {
+    PNP_API_BEGIN
     if (!e || !mu || !sigma_d || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_step: null argument");
     if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_step: denoiser weights not loaded (pnp_load_unet_weights)");
     if (!e->reset_done) return fail(PNP_ERR_STATE, "pnp_step: pnp_reset has not been called");
+    PNP_ON_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if ((rc = run_unet(e, nullptr, (const float2*)z, (const float2*)u, sigma_d, t_action, x, s))) return rc;
@@ -383,20 +465,26 @@ int pnp_step(pnp_handle e, const float* mu, const float* sigma_d, const float* t
         HIP_TRY(launch_finish(t_action, t_state, done, e->cfg.n, s));
     }
     return PNP_OK;
+    PNP_API_END("pnp_step")
 }
 
 int pnp_denoise(pnp_handle e, const float* x_in, const float* sigma, float* out, void* stream) {
+    PNP_API_BEGIN
     if (!e || !x_in || !sigma || !out) return fail(PNP_ERR_INVALID, "pnp_denoise: null argument");
     if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_denoise: denoiser weights not loaded");
+    PNP_ON_DEVICE(e);
     return run_unet(e, x_in, nullptr, nullptr, sigma, nullptr, out, (hipStream_t)stream);
+    PNP_API_END("pnp_denoise")
 }
 
 int pnp_fft2c(pnp_handle e, const float* in, float* out, int batch, int hh, int ww, int inverse, void* stream) {
+    PNP_API_BEGIN
     if (!e || !in || !out) return fail(PNP_ERR_INVALID, "pnp_fft2c: null argument");
     if (hh != e->cfg.h || ww != e->cfg.w || batch < 1 || batch > e->cfg.n)
         return fail(PNP_ERR_INVALID, "pnp_fft2c: shape [%d,%d,%d] does not fit the engine [%d,%d,%d]", batch, hh, ww,
                     e->cfg.n, e->cfg.h, e->cfg.w);
     if (!is_pow2(hh) || !is_pow2(ww)) return fail(PNP_ERR_INVALID, "pnp_fft2c: power-of-two sizes only");
+    PNP_ON_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     // fft_c = S . FFT . S : fold both shifts into the load/store indices of the two passes
     {
@@ -409,20 +497,27 @@ int pnp_fft2c(pnp_handle e, const float* in, float* out, int batch, int hh, int 
         HIP_TRY(launch_fft_cols_generic((float2*)out, e->plan.tw_h, batch, hh, ww, inverse, hh / 2, hh / 2, s));
     }
     return PNP_OK;
+    PNP_API_END("pnp_fft2c")
 }
 
 int pnp_prox_dual(pnp_handle e, const float* mu, const float* t_action, const float* x, float* z, float* u,
                   void* stream) {
+    PNP_API_BEGIN
     if (!e || !mu || !x || !z || !u) return fail(PNP_ERR_INVALID, "pnp_prox_dual: null argument");
     if (!e->reset_done) return fail(PNP_ERR_STATE, "pnp_prox_dual: pnp_reset has not been called");
+    PNP_ON_DEVICE(e);
     return run_prox_dual(e, mu, t_action, x, (float2*)z, (float2*)u, (hipStream_t)stream);
+    PNP_API_END("pnp_prox_dual")
 }
 
 int pnp_psnr(pnp_handle e, const float* x, const float* gt, float* out, void* stream) {
+    PNP_API_BEGIN
     if (!e || !x || !gt || !out) return fail(PNP_ERR_INVALID, "pnp_psnr: null argument");
+    PNP_ON_DEVICE(e);
     Prof p(e, (hipStream_t)stream, 5, -1);
     HIP_TRY(launch_psnr(x, gt, out, e->cfg.n, e->cfg.h * e->cfg.w, (hipStream_t)stream));
     return PNP_OK;
+    PNP_API_END("pnp_psnr")
 }
 
 size_t pnp_snapshot_bytes(pnp_handle e) {
@@ -433,7 +528,9 @@ size_t pnp_snapshot_bytes(pnp_handle e) {
 
 int pnp_snapshot(pnp_handle e, const float* x, const float* z, const float* u, const float* t_state, void* dst,
                  void* stream) {
+    PNP_API_BEGIN
     if (!e || !x || !z || !u || !dst) return fail(PNP_ERR_INVALID, "pnp_snapshot: null argument");
+    PNP_ON_DEVICE(e);
     const size_t px = (size_t)e->cfg.n * e->cfg.h * e->cfg.w;
     char* d = static_cast<char*>(dst);
     hipStream_t s = (hipStream_t)stream;
@@ -443,10 +540,13 @@ int pnp_snapshot(pnp_handle e, const float* x, const float* z, const float* u, c
     if (t_state) HIP_TRY(hipMemcpyAsync(d + px * 20, t_state, (size_t)e->cfg.n * 4, hipMemcpyDeviceToDevice, s));
     else HIP_TRY(hipMemsetAsync(d + px * 20, 0, (size_t)e->cfg.n * 4, s));
     return PNP_OK;
+    PNP_API_END("pnp_snapshot")
 }
 
 int pnp_restore(pnp_handle e, const void* src, float* x, float* z, float* u, float* t_state, void* stream) {
+    PNP_API_BEGIN
     if (!e || !x || !z || !u || !src) return fail(PNP_ERR_INVALID, "pnp_restore: null argument");
+    PNP_ON_DEVICE(e);
     const size_t px = (size_t)e->cfg.n * e->cfg.h * e->cfg.w;
     const char* d = static_cast<const char*>(src);
     hipStream_t s = (hipStream_t)stream;
@@ -455,11 +555,14 @@ int pnp_restore(pnp_handle e, const void* src, float* x, float* z, float* u, flo
     HIP_TRY(hipMemcpyAsync(u, d + px * 12, px * 8, hipMemcpyDeviceToDevice, s));
     if (t_state) HIP_TRY(hipMemcpyAsync(t_state, d + px * 20, (size_t)e->cfg.n * 4, hipMemcpyDeviceToDevice, s));
     return PNP_OK;
+    PNP_API_END("pnp_restore")
 }
 
 int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, int* ww, void* stream) {
+    PNP_API_BEGIN
     if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
     if (which == 8 && e->fuse_last) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 8 is fused away; create the handle with PNP_FLAG_KEEP_STAGES");
+    PNP_ON_DEVICE(e);
     // stage outputs: inc, down1..4 live in lv[k].s; up1..4 in lv[3..0].p
     const int lvl = which <= 4 ? which : 8 - which;
     const LevelBufs& L = e->lv[lvl];
@@ -469,25 +572,32 @@ int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, in
     if (ww) *ww = L.w;
     if (dst) HIP_TRY(launch_nhwc_to_nchw(src, dst, e->cfg.n, L.c, L.h, L.w, (hipStream_t)stream));
     return PNP_OK;
+    PNP_API_END("pnp_unet_read_stage")
 }
 
 int pnp_conv_algorithms(pnp_handle e, int32_t* algo28) {
+    PNP_API_BEGIN
     if (!e || !algo28) return fail(PNP_ERR_INVALID, "pnp_conv_algorithms: null argument");
-    if (!e->weights_loaded) return fail(PNP_ERR_STATE, "pnp_conv_algorithms: weights not loaded");
+    if (e->cfg.flags & PNP_FLAG_NO_DENOISER) return fail(PNP_ERR_STATE, "pnp_conv_algorithms: handle has no denoiser");
     for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? 1 : 0));
     return PNP_OK;
+    PNP_API_END("pnp_conv_algorithms")
 }
 
 int pnp_profile_reset(pnp_handle e) {
+    PNP_API_BEGIN
     if (!e) return fail(PNP_ERR_INVALID, "null handle");
     e->ev_used = 0;
     memset(e->cls_ms, 0, sizeof e->cls_ms); memset(e->cls_n, 0, sizeof e->cls_n);
     memset(e->layer_ms, 0, sizeof e->layer_ms); memset(e->layer_n, 0, sizeof e->layer_n);
     return PNP_OK;
+    PNP_API_END("pnp_profile_reset")
 }
 
 int pnp_profile_collect(pnp_handle e, double* total_ms, int64_t* launches) {
+    PNP_API_BEGIN
     if (!e) return fail(PNP_ERR_INVALID, "null handle");
+    PNP_ON_DEVICE(e);
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->events[i].a, e->events[i].b));
@@ -501,15 +611,18 @@ int pnp_profile_collect(pnp_handle e, double* total_ms, int64_t* launches) {
         if (launches) launches[i] = e->cls_n[i];
     }
     return PNP_OK;
+    PNP_API_END("pnp_profile_collect")
 }
 
 int pnp_profile_layers(pnp_handle e, double* layer_ms, int64_t* layer_launches) {
+    PNP_API_BEGIN
     if (!e) return fail(PNP_ERR_INVALID, "null handle");
     for (int i = 0; i < N_LAYERS; ++i) {
         if (layer_ms) layer_ms[i] = e->layer_ms[i];
         if (layer_launches) layer_launches[i] = e->layer_n[i];
     }
     return PNP_OK;
+    PNP_API_END("pnp_profile_layers")
 }
 
 }  // extern "C"

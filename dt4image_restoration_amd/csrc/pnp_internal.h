@@ -3,9 +3,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include <vector>
 
 namespace pnp {
+
+// Experiment / test overrides, read from the environment ONCE per handle (pnp_create) and stored with it, so the plan a
+// layer's weights were packed for is the plan every later launch uses.
+struct Tuning {
+    int wino_min_cin = 32;        // PNP_WINO_MIN_CIN
+    long wino_min_blocks = 192;   // PNP_WINO_MIN_BLOCKS (tests force 1: Winograd on small problems too)
+    bool wino_big = false;        // PNP_WINO_BIG_GROUPS: the 8-wave plans everywhere
+    bool wino_small = false;      // PNP_WINO_SMALL_GROUPS
+    bool no_wino = false;         // PNP_NO_WINOGRAD
+    int f4_min_cin = 128;         // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
+    bool no_f4 = false;           // PNP_NO_WINO_F4
+};
+Tuning tuning_from_env();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per DEVICE (the attribute lives with the device's
+// code object), not once per process: one bit per device ordinal.
+struct DeviceOnce { std::atomic<uint64_t> mask{0}; };
+hipError_t raise_lds_cap(const void* fn, int bytes, DeviceOnce& once);
 
 // ---- denoiser conv layer description (mirrors dt4image_restoration_amd/unet_spec.py) ----------
 enum SrcMode : int { SRC_PLAIN = 0, SRC_SIGMA = 1, SRC_POOL = 2, SRC_UPCAT = 3 };
@@ -40,8 +59,6 @@ struct ConvArgs {
 
 // Launch the conv3x3 (+bias +LeakyReLU 0.2) implicit-GEMM kernel matching `a` (picks the tile shape
 // from W and Cout).  Returns hipSuccess or the launch error.
-hipError_t launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s);
-
 // Tile plan of a conv3x3 launch (picked from the problem size and Cout).
 struct ConvPlan {
     int tw, th;        // pixel tile
@@ -52,8 +69,9 @@ struct ConvPlan {
     int tiles_x, tiles_y;
 };
 ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
-size_t conv3x3_partial_floats(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
-bool conv3x3_pooled_output_ok(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
+size_t conv3x3_partial_floats(const ConvPlan& p, int N, int H, int W, int Cout);
+bool conv3x3_pooled_output_ok(const ConvPlan& p);
+hipError_t launch_conv3x3(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s);
 
 // Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
 // layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.
@@ -66,10 +84,10 @@ struct WinoPlan {
     bool use;          // layer is eligible (long K, enough workgroups)
     int tw, th, bn, wm, wn, ck, tiles_x, tiles_y;
 };
-WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout);
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, const Tuning& t);
 size_t winograd_pack_floats(int cin, int cout);
 void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* dst);
-hipError_t launch_conv3x3_winograd(const ConvArgs& a, int src_mode, hipStream_t s);
+hipError_t launch_conv3x3_winograd(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s);
 
 // First layer (2 -> 32, K = 18: too thin for MFMA, direct VALU) and last layer (1x1 32 -> 1 fused
 // with the residual add and clamp).  `ximg` (f32 [N,H,W]) or, when null, Re(z-u) of complex64 z,u
@@ -102,6 +120,7 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
 hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
                                     const float* tact, int N, int H, int W, hipStream_t s);
 
+// x0 / x / z / u may all be null: only the episode constants (y0s, masks) are rebuilt
 hipError_t launch_reset(const float2* x0, const float2* y0, const uint8_t* mask, int mask_n, float* x, float2* z,
                         float2* u, float2* y0s, uint8_t* masks, int N, int H, int W, hipStream_t s);
 hipError_t launch_finish(const float* tact, float* tstate, uint8_t* done, int N, hipStream_t s);

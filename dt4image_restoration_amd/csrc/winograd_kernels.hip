@@ -70,18 +70,17 @@ void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* 
 // Eligibility + tile plan.  The transforms and the 16-accumulator epilogue are per-item overhead that long K amortises
 // best (1.65x over the direct kernel at Cin >= 128), but even the K = 288 layers gain ~9 %; small problems (too few
 // workgroups) stay on the direct kernel with split-K.
-WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, const Tuning& t) {
     WinoPlan p{};
     p.use = false;
-    const int min_cin = getenv("PNP_WINO_MIN_CIN") ? atoi(getenv("PNP_WINO_MIN_CIN")) : 32;   // experiments: raise to compare
-    if (Cin < min_cin || Cin % 32 || Cout % 32) return p;
+    if (t.no_wino || Cin < t.wino_min_cin || Cin % 32 || Cout % 32) return p;
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     // Cout >= 128: one 8-wave workgroup per CU (32 tiles x 128 channels, 32-channel chunks).  Cout = 64 / 32: 4-wave
     // workgroups (32 tiles x 64 channels / 64 tiles x 32 channels) small enough for TWO per CU, so one workgroup's
     // barriers, transforms, prologue loads and epilogue run under the other's MFMAs - their chunks are short (64 / 32
     // MFMAs per wave), which made per-chunk overhead the bound with a single resident workgroup.
-    const bool big = getenv("PNP_WINO_BIG_GROUPS") != nullptr;          // experiments: the 8-wave plans everywhere
-    if (Cout % 128 == 0 && getenv("PNP_WINO_SMALL_GROUPS") == nullptr) { p.wm = 1; p.wn = 4; p.ck = 32; }
+    const bool big = t.wino_big;                                        // experiments: the 8-wave plans everywhere
+    if (Cout % 128 == 0 && !t.wino_small) { p.wm = 1; p.wn = 4; p.ck = 32; }
     else if (Cout % 64 == 0) { if (big) { p.wm = 2; p.wn = 2; } else { p.wm = 1; p.wn = 2; } p.ck = 16; }
     else { if (big) { p.wm = 4; p.wn = 1; } else { p.wm = 2; p.wn = 1; } p.ck = 8; }
     const int tc = p.tw / 2, tr = 32 / tc;
@@ -90,8 +89,7 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout) {
     p.tiles_x = (W + p.tw - 1) / p.tw;
     p.tiles_y = (H + p.th - 1) / p.th;
     const long blocks = (long)p.tiles_x * p.tiles_y * N * (Cout / p.bn);
-    const long min_blocks = getenv("PNP_WINO_MIN_BLOCKS") ? atol(getenv("PNP_WINO_MIN_BLOCKS")) : 192;   // tests force 1
-    p.use = blocks >= min_blocks;
+    p.use = blocks >= t.wino_min_blocks;
     return p;
 }
 
@@ -451,12 +449,8 @@ static hipError_t launch_wino_inst(const ConvArgs& a, const WinoPlan& p, hipStre
     constexpr size_t lds_x = (size_t)(2 * WM * WN) * 16 * 2 * 64 * sizeof(float);   // cross-wave exchange of the output transform
     constexpr size_t lds = (lds_main > lds_out ? lds_main : lds_out) > lds_x ? (lds_main > lds_out ? lds_main : lds_out) : lds_x;
     auto kern = conv3x3_winograd_kernel<TW, WM, WN, CK, SRC>;
-    static bool cap = false;
-    if (!cap) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        cap = true;
-    }
+    static DeviceOnce cap;
+    if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn));
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 128), lds, s, a);
     return hipGetLastError();
@@ -482,8 +476,7 @@ static hipError_t launch_wino_tw(const ConvArgs& a, const WinoPlan& p, int src_m
 }
 
 // `a.wpack` must be the Winograd pack (pack_winograd_weights with the plan's ck).
-hipError_t launch_conv3x3_winograd(const ConvArgs& a0, int src_mode, hipStream_t s) {
-    const WinoPlan p = winograd_plan(a0.N, a0.H, a0.W, a0.Cin, a0.Cout);
+hipError_t launch_conv3x3_winograd(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
     if (!p.use) return hipErrorInvalidValue;
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;

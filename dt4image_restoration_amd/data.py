@@ -33,27 +33,32 @@ def normalised_rtg(target: float, flex: bool = False) -> float:
 
 
 def save_mat(path: str, problem: Dict[str, np.ndarray], index: int = 0) -> None:
-    """Write slice `index` of a `synthetic.make_problem` dict in the reference's `.mat` layout."""
+    """Write slice `index` of a `synthetic.make_problem` dict in the reference's `.mat` layout.  `x0` is stored as the
+    raw zero-filled reconstruction (= ATy0, negative pixels included), as a TFPnP-style file holds it; the loader clips."""
     from scipy.io import savemat
-    savemat(path, {"x0": problem["x0"][index], "y0": problem["y0"][index], "ATy0": problem["ATy0"][index],
+    savemat(path, {"x0": problem["ATy0"][index], "y0": problem["y0"][index], "ATy0": problem["ATy0"][index],
                    "mask": problem["mask"].astype(np.uint8), "gt": problem["gt"][index]})
 
 
 def load_mat(path: str) -> Dict[str, np.ndarray]:
-    """One image as the reference's datasets return it (datasets.py:153-160,191-199): x0 clipped at 0."""
+    """One image as the reference's datasets return it (datasets.py:153-160,191-199): `x0` clipped at 0 is what the
+    environment gets (`action_dict['x0']`, :160,199), while the policy's first state token is the UNclipped real part
+    of the stored x0 (:162,201 read `mat['x0'][..., 0]` after the clip only rebound the dict entry) - kept here as
+    `x0_raw` [..,H,W] so a reference checkpoint sees the same first observation."""
     from scipy.io import loadmat
     mat = loadmat(path)
     missing = [k for k in _MAT_KEYS if k not in mat]
     if missing:
         raise KeyError(f"{path}: missing keys {missing}")
     out = {k: np.asarray(mat[k]) for k in _MAT_KEYS}
+    out["x0_raw"] = np.array(out["x0"][..., 0], dtype=np.float32)
     out["x0"] = np.clip(out["x0"], a_min=0, a_max=None)
     return out
 
 
 def load_dir(data_dir: str, limit: int = 0) -> Tuple[Dict[str, np.ndarray], List[str]]:
     """All `.mat` files of a directory (sorted, datasets.py:146-147) stacked into one batch dict
-    {x0,y0,ATy0: [N,1,H,W,2], mask [H,W], gt [N,1,H,W]} + their task names."""
+    {x0,y0,ATy0: [N,1,H,W,2], mask [H,W], gt [N,1,H,W], x0_raw [N,1,H,W]} + their task names."""
     fns = sorted(f for f in os.listdir(data_dir) if f.endswith(".mat"))
     if limit:
         fns = fns[:limit]
@@ -66,6 +71,7 @@ def load_dir(data_dir: str, limit: int = 0) -> Tuple[Dict[str, np.ndarray], List
             raise ValueError(f"{f}: all files of one batch must share size and sampling mask")
     batch = {k: np.stack([it[k].reshape(1, h, w, 2) for it in items]).astype(np.float32) for k in ("x0", "y0", "ATy0")}
     batch["gt"] = np.stack([it["gt"].reshape(1, h, w) for it in items]).astype(np.float32)
+    batch["x0_raw"] = np.stack([it["x0_raw"].reshape(1, h, w) for it in items]).astype(np.float32)
     batch["mask"] = items[0]["mask"].reshape(h, w) != 0
     return batch, [task_from_filename(f) for f in fns]
 

@@ -118,12 +118,13 @@ class GreedyEvaluator:
     def run(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
             first_state: Optional[torch.Tensor] = None) -> GreedyResult:
         """mat: collated `.mat` dict (x0, y0, ATy0, mask, gt); rtg [N] normalised return-to-go target;
-        task [N] int task token; first_state [N, H*W] (default Re x0, datasets.py:162-163)."""
+        task [N] int task token; first_state [N, H*W]: the policy's first state token - default `mat['x0_raw']`, the
+        UNclipped Re x0 the reference's datasets hand over (datasets.py:162,201), else the env's (clipped) Re x0."""
         dev = self.device
         states = self.env.reset(mat, dev)
         n = states["z"].shape[0]
         if first_state is None:
-            first_state = states["x"]
+            first_state = torch.as_tensor(mat["x0_raw"]) if "x0_raw" in mat else states["x"]
         if first_state.is_complex():
             first_state = first_state.real
         es, ea, er, et, ek = self.buffers(n, task)

@@ -18,8 +18,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_episode_counter = 0
+
+
+def _next_episode() -> int:
+    """Process-wide id of one `reset` (one set of k-space constants): states carry it, engines remember the live one."""
+    global _episode_counter
+    _episode_counter += 1
+    return _episode_counter
 
 
 class PnPEngine:
@@ -42,6 +48,11 @@ class PnPEngine:
         self._h = hnd
         self.profile = profile or profile_layers
         self.bf16_convs = bool(bf16_convs)
+        self.live_episode = 0        # id of the reset whose y0 / mask the engine currently holds (0: none)
+
+    def _stream(self) -> int:
+        """The caller's current stream ON THE ENGINE'S DEVICE (not on torch's current device)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def close(self):
         if getattr(self, "_h", None):
@@ -94,8 +105,22 @@ class PnPEngine:
         z = torch.empty((self.n, 1, self.h, self.w), dtype=torch.complex64, device=self.device)
         u = torch.empty_like(z)
         _lib.check(self.lib.pnp_reset(self._h, x0.data_ptr(), y0.data_ptr(), m.data_ptr(), mask_n, x.data_ptr(),
-                                      z.data_ptr(), u.data_ptr(), _stream()), "pnp_reset")
+                                      z.data_ptr(), u.data_ptr(), self._stream()), "pnp_reset")
+        self.live_episode = _next_episode()
         return x, z, u
+
+    def set_kspace(self, y0: torch.Tensor, mask: torch.Tensor, episode: int = 0) -> None:
+        """Re-install the k-space constants (y0, mask) of another episode without touching any iterate
+        (pnp_set_kspace); `episode` = the id that episode's reset returned (0: a fresh id)."""
+        nhw = self.n * self.h * self.w
+        y0 = self._chk(y0, torch.complex64, nhw, "y0")
+        m = mask.to(torch.uint8).contiguous()
+        if m.numel() not in (self.h * self.w, nhw):
+            raise ValueError(f"mask: expected {self.h * self.w} or {nhw} elements, got {tuple(mask.shape)}")
+        self._chk(m, torch.uint8, m.numel(), "mask")
+        _lib.check(self.lib.pnp_set_kspace(self._h, y0.data_ptr(), m.data_ptr(), 1 if m.numel() == self.h * self.w else self.n,
+                                           self._stream()), "pnp_set_kspace")
+        self.live_episode = episode or _next_episode()
 
     def step(self, x: torch.Tensor, z: torch.Tensor, u: torch.Tensor, mu: torch.Tensor, sigma_d: torch.Tensor,
              t_action: Optional[torch.Tensor] = None, t_state: Optional[torch.Tensor] = None,
@@ -108,7 +133,7 @@ class PnPEngine:
         if t_state is not None: self._chk(t_state, torch.float32, self.n, "t_state")
         if done is not None: self._chk(done, torch.uint8, self.n, "done")
         _lib.check(self.lib.pnp_step(self._h, mu.data_ptr(), sigma_d.data_ptr(), _ptr(t_action), x.data_ptr(),
-                                     z.data_ptr(), u.data_ptr(), _ptr(t_state), _ptr(done), _stream()), "pnp_step")
+                                     z.data_ptr(), u.data_ptr(), _ptr(t_state), _ptr(done), self._stream()), "pnp_step")
 
     def denoise(self, x: torch.Tensor, sigma: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         nhw = self.n * self.h * self.w
@@ -116,7 +141,7 @@ class PnPEngine:
         if out is None:
             out = torch.empty_like(x)
         self._chk(out, torch.float32, nhw, "out")
-        _lib.check(self.lib.pnp_denoise(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), _stream()), "pnp_denoise")
+        _lib.check(self.lib.pnp_denoise(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), self._stream()), "pnp_denoise")
         return out
 
     def fft2c(self, img: torch.Tensor, inverse: bool = False) -> torch.Tensor:
@@ -126,7 +151,7 @@ class PnPEngine:
         img = self._chk(img, torch.complex64, batch * self.h * self.w, "img")
         out = torch.empty_like(img)
         _lib.check(self.lib.pnp_fft2c(self._h, img.data_ptr(), out.data_ptr(), batch, self.h, self.w, int(inverse),
-                                      _stream()), "pnp_fft2c")
+                                      self._stream()), "pnp_fft2c")
         return out
 
     def prox_dual(self, x, z, u, mu, t_action=None) -> None:
@@ -134,13 +159,13 @@ class PnPEngine:
         self._chk(x, torch.float32, nhw, "x"); self._chk(z, torch.complex64, nhw, "z"); self._chk(u, torch.complex64, nhw, "u")
         self._chk(mu, torch.float32, self.n, "mu")
         _lib.check(self.lib.pnp_prox_dual(self._h, mu.data_ptr(), _ptr(t_action), x.data_ptr(), z.data_ptr(),
-                                          u.data_ptr(), _stream()), "pnp_prox_dual")
+                                          u.data_ptr(), self._stream()), "pnp_prox_dual")
 
     def psnr(self, x: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
         nhw = self.n * self.h * self.w
         self._chk(x, torch.float32, nhw, "x"); self._chk(gt, torch.float32, nhw, "gt")
         out = torch.empty(self.n, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pnp_psnr(self._h, x.data_ptr(), gt.data_ptr(), out.data_ptr(), _stream()), "pnp_psnr")
+        _lib.check(self.lib.pnp_psnr(self._h, x.data_ptr(), gt.data_ptr(), out.data_ptr(), self._stream()), "pnp_psnr")
         return out
 
     def snapshot(self, x: torch.Tensor, z: torch.Tensor, u: torch.Tensor, t_state: Optional[torch.Tensor] = None,
@@ -156,7 +181,7 @@ class PnPEngine:
         elif out.numel() * out.element_size() != nbytes or not out.is_contiguous() or out.device != self.device:
             raise ValueError(f"snapshot buffer must be {nbytes} contiguous bytes on {self.device}")
         _lib.check(self.lib.pnp_snapshot(self._h, x.data_ptr(), z.data_ptr(), u.data_ptr(), _ptr(t_state), out.data_ptr(),
-                                         _stream()), "pnp_snapshot")
+                                         self._stream()), "pnp_snapshot")
         return out
 
     def restore(self, snap: torch.Tensor, x: torch.Tensor, z: torch.Tensor, u: torch.Tensor,
@@ -168,14 +193,14 @@ class PnPEngine:
         if snap.numel() * snap.element_size() != self.lib.pnp_snapshot_bytes(self._h) or not snap.is_contiguous():
             raise ValueError("not a snapshot of this engine")
         _lib.check(self.lib.pnp_restore(self._h, snap.data_ptr(), x.data_ptr(), z.data_ptr(), u.data_ptr(), _ptr(t_state),
-                                        _stream()), "pnp_restore")
+                                        self._stream()), "pnp_restore")
 
     def read_stage(self, which: int) -> torch.Tensor:
         c, hh, ww = C.c_int(), C.c_int(), C.c_int()
-        _lib.check(self.lib.pnp_unet_read_stage(self._h, which, None, C.byref(c), C.byref(hh), C.byref(ww), _stream()),
+        _lib.check(self.lib.pnp_unet_read_stage(self._h, which, None, C.byref(c), C.byref(hh), C.byref(ww), self._stream()),
                    "pnp_unet_read_stage")
         out = torch.empty((self.n, c.value, hh.value, ww.value), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pnp_unet_read_stage(self._h, which, out.data_ptr(), None, None, None, _stream()),
+        _lib.check(self.lib.pnp_unet_read_stage(self._h, which, out.data_ptr(), None, None, None, self._stream()),
                    "pnp_unet_read_stage")
         return out
 

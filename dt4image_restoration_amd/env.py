@@ -13,6 +13,10 @@ Differences, all documented in DESIGN.md:
   * states['x'] is float32 from reset on (the reference holds complex x0 until the first step;
     every caller reads `.real`, which is a no-op on a real tensor)
   * the ARNIQA scorer (a torch.hub network fetch, env.py:36-40) is replaced by an injectable callable
+  * `step` stays a function of the `states` it is handed (as in the reference, env.py:75,88-90): the engine holds ONE set
+    of pre-shifted k-space constants, and states carry the id of their episode in the private key `_episode`; when
+    states of another episode (another env on the same denoiser, an older reset) are stepped, the shim re-installs that
+    episode's y0 / mask from the dict first (pnp_set_kspace)
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from .denoiser import UNetDenoiser2D
-from .engine import PnPEngine
+from .engine import PnPEngine, _next_episode
 
 
 def _as_complex(t: torch.Tensor) -> torch.Tensor:
@@ -65,7 +69,20 @@ class PnPEnv:
         aty0 = torch.as_tensor(data["ATy0"])[..., 0] if "ATy0" in data else None
         return OrderedDict({"x": x, "y0": y0, "z": z, "u": u, "mask": mask, "gt": gt, "ATy0": aty0,
                             "T": torch.zeros(n, dtype=torch.float32, device=device),
-                            "complex_y0": data["y0"]})
+                            "complex_y0": data["y0"], "_episode": eng.live_episode})
+
+    def _bind_episode(self, eng: PnPEngine, states) -> None:
+        """Make the engine's k-space constants those of `states` (env.py:88-90 reads y0 / mask from the dict)."""
+        ep = states.get("_episode", 0)
+        if ep and ep == eng.live_episode:
+            return
+        if not ep:                              # a state dict built by hand the reference's way
+            ep = states["_episode"] = _next_episode()
+        n, h, w = eng.n, eng.h, eng.w
+        y0 = _as_complex(states["y0"]).reshape(n, 1, h, w).to(eng.device).contiguous()
+        mask = torch.as_tensor(states["mask"]).to(eng.device)
+        mask = mask.reshape(h, w) if mask.numel() == h * w else mask.reshape(n, h, w)
+        eng.set_kspace(y0, mask, episode=ep)
 
     def _param(self, v, n: int, device) -> torch.Tensor:
         t = torch.as_tensor(v, dtype=torch.float32, device=device).reshape(-1)
@@ -89,6 +106,7 @@ class PnPEnv:
         if x.is_complex():                      # a state built by hand the reference's way
             x = x.real.contiguous()
         done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._bind_episode(eng, states)
         eng.step(x, z, u, mu, sigma_d, t_action=T, t_state=states["T"], done=done)
         states["x"] = x
         if n == 1:

@@ -91,7 +91,7 @@ def _gauss(seed: int, stream: int, count: int) -> np.ndarray:
 def make_problem(n: int, h: int, w: int, accel: float = 4.0, sigma_n: float = 10.0 / 255.0,
                  seed: int = 1234, first_slice: int = 0) -> Dict[str, np.ndarray]:
     """Collated-batch dict with the `.mat` keys the reference's `PnPEnv.reset` reads
-    (env.py:57-71): x0, y0, ATy0 float32 [n,1,h,w,2]; mask bool [h,w]; gt float32 [n,1,h,w].
+    (env.py:57-71): x0, y0, ATy0 float32 [n,1,h,w,2]; mask bool [h,w]; gt float32 [n,1,h,w]; plus x0_raw [n,1,h,w].
     Slice i depends only on (seed, first_slice + i), so shards of one job agree with the
     unsharded job."""
     mask = radial_mask(h, w, accel)
@@ -109,7 +109,9 @@ def make_problem(n: int, h: int, w: int, accel: float = 4.0, sigma_n: float = 10
         y0[i, 0, ..., 0], y0[i, 0, ..., 1] = y.real, y.imag
         aty0[i, 0, ..., 0], aty0[i, 0, ..., 1] = a.real, a.imag
         x0[i, 0] = np.clip(aty0[i, 0], 0.0, None)           # datasets.py:160
-    return {"x0": x0, "y0": y0, "ATy0": aty0, "mask": mask, "gt": gt}
+    # x0_raw: the UNclipped real part of the zero-filled reconstruction - the policy's first state token in the reference
+    # (datasets.py:162,201 read mat['x0'][..., 0], which the clip at :160,199 does not touch)
+    return {"x0": x0, "y0": y0, "ATy0": aty0, "mask": mask, "gt": gt, "x0_raw": aty0[..., 0].copy()}
 
 
 def param_table(n: int, iters: int, seed: int = 77):

@@ -11,9 +11,14 @@
  * Conventions
  *   - every pointer marked DEVICE is HIP device memory owned by the caller (e.g. a torch-ROCm
  *     tensor's data_ptr()); HOST pointers are ordinary memory.  No torch types cross this ABI.
- *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
- *     no entry point synchronises the device except pnp_create / pnp_load_unet_weights /
- *     pnp_destroy (setup-time).
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) of the
+ *     handle's device; no entry point synchronises the device except pnp_create /
+ *     pnp_load_unet_weights / pnp_destroy (setup-time).  Entry points switch to the handle's device
+ *     for the call and restore the caller's current device before returning.
+ *   - no C++ exception crosses this boundary (PNP_ERR_NOMEM / PNP_ERR_INTERNAL instead), and a failed
+ *     pnp_load_unet_weights leaves the handle exactly as it was (all-or-nothing).
+ *   - tile plans and experiment overrides (PNP_WINO_* environment variables) are fixed per handle at
+ *     pnp_create.
  *   - real data is float32; complex data is complex64 = interleaved (re, im) float32, passed as
  *     float*; images are [N,1,H,W] contiguous exactly like the reference's tensors.
  *   - returns PNP_OK (0) or a negative pnp_status; pnp_last_error() gives the message of the last
@@ -38,7 +43,8 @@ typedef enum {
     PNP_ERR_INVALID = -1,      /* bad argument (NULL, shape, size not supported) */
     PNP_ERR_HIP = -2,          /* a HIP runtime call failed; message has hipGetErrorString */
     PNP_ERR_STATE = -3,        /* call order: weights not loaded / reset not done */
-    PNP_ERR_NOMEM = -4
+    PNP_ERR_NOMEM = -4,        /* host or device allocation failed */
+    PNP_ERR_INTERNAL = -5      /* a C++ exception was caught at the ABI boundary (never propagates to the caller) */
 } pnp_status;
 
 typedef struct {
@@ -88,6 +94,14 @@ int pnp_load_unet_weights(pnp_handle h, const float* blob, size_t n_floats);
  * y0), so `y0`/`mask` need not outlive the call. */
 int pnp_reset(pnp_handle h, const float* x0, const float* y0, const uint8_t* mask, int mask_n,
               float* x, float* z, float* u, void* stream);
+
+/* Replaces: the reference's `states['y0']` / `states['mask']` travelling WITH the state dict
+ * (evaluation/env.py:71: every `step` reads them from the dict it is handed, :88-90).  The engine keeps ONE set of
+ * episode constants; a caller that interleaves episodes on one handle (two environments, a tree search next to a
+ * greedy rollout) re-installs the constants of the episode it is about to step.  Same arguments and pre-shift as
+ * pnp_reset, the iterate (x, z, u) is not touched.  The Python shim calls it automatically when the `states` it is
+ * handed belong to another episode than the engine's live one. */
+int pnp_set_kspace(pnp_handle h, const float* y0, const uint8_t* mask, int mask_n, void* stream);
 
 /* Replaces: PnPEnv.step (evaluation/env.py:74-100), batched over the N resident slices.
  *   mu, sigma_d : DEVICE float32 [N]  per-slice penalty and denoiser noise level (action_dict)

@@ -32,7 +32,12 @@ from gen_golden import import_reference, ref_denoiser  # noqa: E402
 # (name, policy seed, stop-logit bias, action-head gain, rtg target, task)
 CASES = [("full30", 0, -3.0, 8.0, 10.0, "4x_10"),
          ("stop_now", 1, +3.0, 8.0, 10.0, "4x_10"),
-         ("stop_mid", 7, 0.0, 12.0, 10.0, "4x_15")]           # found by the search below (kept for re-runs: pseed=None)
+         ("stop_mid", 7, 0.0, 12.0, 10.0, "4x_15"),           # found by the search below (kept for re-runs: pseed=None)
+         # the policy's first state token as the reference's datasets build it from a file whose stored x0 is the raw
+         # zero-filled reconstruction (negative pixels): UNclipped Re x0 (datasets.py:162,201), while the environment gets
+         # the clipped copy (:160,199)
+         ("raw_first", 0, -3.0, 8.0, 10.0, "4x_10")]
+RAW_FIRST = {"raw_first"}
 
 
 def main():
@@ -48,7 +53,7 @@ def main():
     env.denoiser = ref_denoiser(UNetDenoiser2D, sd_unet)
     problem = synthetic.make_problem(1, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
 
-    def run_case(pseed, t_bias, gain, rtg_target, task):
+    def run_case(pseed, t_bias, gain, rtg_target, task, raw_first=False):
         model = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
         sd = weights.generate_policy_weights(model, pseed, t_bias=t_bias, head_gain=gain)
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
@@ -60,7 +65,7 @@ def main():
         finally:
             os.unlink(path)
         # what EvaluationOptimalDataset.__getitem__ + DataLoader(batch_size=1) hand over (datasets.py:181-207)
-        x0 = problem["x0"][0]
+        x0 = problem["ATy0"][0] if raw_first else problem["x0"][0]
         states = torch.from_numpy(x0[..., 0].reshape(1, 1, -1).copy())
         rtg = torch.tensor([[[D.normalised_rtg(rtg_target)]]], dtype=torch.float32)
         task_t = torch.tensor([[D.OPTIMAL_TASKS.index(task)]])
@@ -102,7 +107,7 @@ def main():
             assert found, "no mid-episode stop found"
             pseed, t_bias, gain, r = found
         else:
-            r = run_case(pseed, t_bias, gain, rtg_target, task)
+            r = run_case(pseed, t_bias, gain, rtg_target, task, raw_first=name in RAW_FIRST)
         print(name, "seed", pseed, "t_bias", t_bias, "stop time", int(r["time"]), "reward", float(r["reward"]),
               "min |T-0.5|", float(np.abs(r["handed"][:, 0] - 0.5).min()))
         for k, v in r.items():

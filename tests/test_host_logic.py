@@ -67,17 +67,55 @@ def test_create_rejects_bad_config_without_touching_a_gpu():
     assert lib.pnp_create(None, C.byref(h)) == -1
 
 
-def test_product_path_has_no_cpu_fallback():
+def test_product_path_never_touches_the_oracle():
+    """Nothing under the package (sub-packages and the C sources included) imports, names or links the oracle; only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg may."""
+    pkg = os.path.join(ROOT, "dt4image_restoration_amd")
+    seen = 0
+    for dirpath, _dirs, files in os.walk(pkg):
+        if "__pycache__" in dirpath or os.path.basename(dirpath) in ("_asan", "_stamps"):
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".c")) or fn == "Makefile":
+                seen += 1
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text and "pnp_ref" not in text, os.path.join(dirpath, fn)
+    assert seen >= 18                                    # top-level modules + drivers/ + csrc/
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and "def cpu_baseline" in bench      # one import, inside the baseline leg
+
+
+def test_product_path_fails_loudly_without_a_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from dt4image_restoration_amd.engine import PnPEngine
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.env import PnPEnv
     with pytest.raises(_lib.PnPError):
         PnPEngine(1, 64, 64)
-    # and nothing under the package imports the oracle
-    pkg = os.path.join(ROOT, "dt4image_restoration_amd")
-    for fn in os.listdir(pkg):
-        if fn.endswith(".py"):
-            assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("no CPU", ""), fn
+    den = UNetDenoiser2D.seeded(0)
+    with pytest.raises(RuntimeError):
+        den(torch.zeros(1, 1, 32, 32), torch.zeros(1))
+    with pytest.raises(RuntimeError):
+        PnPEnv(30, den, "cuda").reset({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_problem(1, 32, 32).items()}, "cpu")
+
+
+def test_host_side_under_asan_ubsan():
+    """host-side AddressSanitizer + UBSan build of the C ABI (`make asan`: host code instrumented, device code as
+    usual) running tests/asan_host.cpp - every tile plan, every weight repack into exactly-sized heap buffers, and the
+    argument validation of every entry point.  CPU box only (GPU sanitizer runs are not available on the pool)."""
+    import shutil
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("sanitizer build is for the CPU box")
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc / make")
+    csrc = os.path.join(ROOT, "dt4image_restoration_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j", "4", "asan"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(csrc, "_asan", "asan_host")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
 
 
 def test_unet_spec_counts():
