@@ -181,7 +181,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         const int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;
-        if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[li], src_mode, s));
+        if (e->wino[li] && e->wplan[li].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[li], src_mode, s));
+        else if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[li], src_mode, s));
         else HIP_TRY(launch_conv3x3(a, e->cplan[li], src_mode, s));
         return PNP_OK;
     };
@@ -283,7 +284,12 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
         for (int li = 1; li < N_LAYERS - 1; ++li) {
             const LayerSpec& L = kLayers[li];
             const int lh = cfg->h >> L.level, lw = cfg->w >> L.level;
-            e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, e->tune);
+            // the source mode the launch will use: a pooled stage input is read PLAIN from the producer's pooled copy, which
+            // exists iff the producing layer (li - 1, planned just before) runs a Winograd kernel or the direct LDS-epilogue plan
+            int src_mode = L.src;
+            if (L.src == SRC_POOL && (lh * 2) % 2 == 0 && (e->wino[li - 1] || conv3x3_pooled_output_ok(e->cplan[li - 1])))
+                src_mode = SRC_PLAIN;
+            e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, e->tune);
             e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16);
             e->wino[li] = e->wplan[li].use && !bf16;
             if (e->wino[li]) continue;
@@ -389,6 +395,11 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
             const float* src;
             if (li == 0 || li == N_LAYERS - 1) {   // first (2->32, OIHW as is) and last (1x1) layers
                 pf = nw; src = w;
+            } else if (e->wino[li] && e->wplan[li].algo == 4) {
+                pf = winograd4_pack_floats(L.cin, L.cout);
+                tmp.assign(pf, 0.f);
+                pack_winograd4_weights(w, L.cin, L.cout, tmp.data());
+                src = tmp.data();
             } else if (e->wino[li]) {
                 pf = winograd_pack_floats(L.cin, L.cout);
                 tmp.assign(pf, 0.f);
@@ -579,7 +590,7 @@ int pnp_conv_algorithms(pnp_handle e, int32_t* algo28) {
     PNP_API_BEGIN
     if (!e || !algo28) return fail(PNP_ERR_INVALID, "pnp_conv_algorithms: null argument");
     if (e->cfg.flags & PNP_FLAG_NO_DENOISER) return fail(PNP_ERR_STATE, "pnp_conv_algorithms: handle has no denoiser");
-    for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? 1 : 0));
+    for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? e->wplan[i].algo : 0));
     return PNP_OK;
     PNP_API_END("pnp_conv_algorithms")
 }

@@ -82,9 +82,14 @@ void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, flo
 // Winograd F(2x2,3x3) path for the K-heavy layers (winograd_kernels.hip).
 struct WinoPlan {
     bool use;          // layer is eligible (long K, enough workgroups)
+    int algo;          // 1: F(2x2,3x3) (winograd_kernels.hip), 4: F(4x4,3x3) (winograd4_kernels.hip)
     int tw, th, bn, wm, wn, ck, tiles_x, tiles_y;
 };
-WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, const Tuning& t);
+// `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t);
+size_t winograd4_pack_floats(int cin, int cout);
+void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst);
+hipError_t launch_conv3x3_winograd4(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s);
 size_t winograd_pack_floats(int cin, int cout);
 void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* dst);
 hipError_t launch_conv3x3_winograd(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s);

@@ -1,0 +1,467 @@
+// Winograd F(4x4, 3x3) convolution for the K-heavy denoiser layers (Cin >= 128) on gfx950 (MI355X).
+//
+// Same operator as conv3x3_winograd_kernel / conv3x3_mfma_kernel (conv3x3 s1 p1 + bias + LeakyReLU(0.2),
+// /root/reference/evaluation/noise.py:75-98, the stage's bilinear-upsample+concat input transform applied while staging),
+// computed with  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 4x4 output tile: 36 multiplies per 16 outputs and (cin, cout)
+// pair instead of 144 (direct) or 64 (F(2x2)) - 1.78x fewer MFMAs than F(2x2) on layers whose bound is the f32 matrix pipe.
+//
+// Interpolation points (0, +-3/4, +-3/2, inf) instead of the textbook (0, +-1, +-2, inf): every transform coefficient stays
+// a dyadic rational (exact in f32) and the f32 error of a 256-channel layer drops from 9.8e-6 to 1.9e-6 of the output scale
+// (3x the F(2x2) kernel's, 6x the direct sum's; tools/wino_points.py scans the candidates).  All arithmetic is f32; the
+// weight transform G g G^T is done once on the host in f64.
+//
+// Workgroup = 8 waves = 4 frequency quadrants (3x3 blocks of the 6x6 frequency grid) x 2 groups of 32 output channels,
+// working on 32 tiles (512 output pixels) x 64 channels; every wave holds 9 accumulators of 32 tiles x 32 channels
+// (144 registers), two waves per SIMD.  Per 16-channel chunk:
+//   1. stage the (TH+2) x (TW+2) halo patch in LDS (loads of chunk c+1 in flight during chunk c's MFMAs; upsampled chunks
+//      come from the tile's low-res source region parked in LDS, like the F(2x2) kernel)
+//   2. input transform: thread (tile, 4 channels, quadrant) reads the 5x5 part of the 6x6 window its quadrant needs and
+//      writes the 9 frequency planes V[xi][tile][channel] its own wave pair consumes
+//   3. 36 independent GEMMs, 9 per wave: acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment, transformed
+//      weights streamed from L2 in pre-packed per-lane order)
+// Output transform: every wave turns its 3x3 block of M into a PARTIAL 4x4 output tile (lane-local), the four partials
+// meet in LDS and are summed in a fixed order (bit-reproducible) by threads that own (2x2 pixel window, 4 channels):
+// + bias, LeakyReLU, 16-byte NHWC stores and the 2x2 max-pooled copy for the next stage from the same registers.
+#include "pnp_internal.h"
+#include "conv_staging.h"
+
+namespace pnp {
+
+namespace {
+// points (0, +-a, +-b, inf), a = 3/4, b = 3/2
+constexpr double kA = 0.75, kB = 1.5;
+constexpr float fA = 0.75f, fB = 1.5f, fA2 = 0.5625f, fB2 = 2.25f, fA3 = 0.421875f, fB3 = 3.375f;
+constexpr float fK0 = 1.265625f;      // a^2 b^2
+constexpr float fK1 = 2.8125f;        // a^2 + b^2
+constexpr float fAB2 = 1.6875f;       // a b^2
+constexpr float fA2B = 0.84375f;      // a^2 b
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// One-dimensional input transform, three of the six outputs.  B^T rows (ascending powers of the window index):
+//   0: [a^2 b^2, 0, -(a^2+b^2), 0, 1, 0]   1,2: [0, -+a b^2, -b^2, +-a, 1, 0]
+//   3,4: [0, -+a^2 b, -a^2, +-b, 1, 0]     5: [0, a^2 b^2, 0, -(a^2+b^2), 0, 1]
+// G = 0: outputs 0,1,2 from d[0..4];  G = 1: outputs 3,4,5 from d[1..5] (d is indexed by window position either way).
+template <int G>
+__device__ __forceinline__ void bt3(const v2f* d, v2f* o) {
+    if constexpr (G == 0) {
+        o[0] = fK0 * d[0] + (d[4] - fK1 * d[2]);
+        const v2f e = d[4] - fB2 * d[2];
+        const v2f od = fA * (d[3] - fB2 * d[1]);
+        o[1] = e + od;
+        o[2] = e - od;
+    } else {
+        const v2f e = d[4] - fA2 * d[2];
+        const v2f od = fB * (d[3] - fA2 * d[1]);
+        o[0] = e + od;
+        o[1] = e - od;
+        o[2] = fK0 * d[1] + (d[5] - fK1 * d[3]);
+    }
+}
+
+// Column transform of window row y: three of the six outputs (QJ = 0: frequencies 0..2 from positions 0..4; QJ = 1: 3..5 from 1..5).
+template <int QJ, int PW, int CKP>
+__device__ __forceinline__ void wino4_row(const float* w, int y, v2f* cc) {
+    v2f d[6];
+    constexpr int X0 = QJ == 0 ? 0 : 1;
+    __builtin_amdgcn_sched_barrier(0);                 // one window row in flight at a time
+#pragma unroll
+    for (int x = 0; x < 5; ++x) d[X0 + x] = *reinterpret_cast<const v2f*>(w + (y * PW + X0 + x) * CKP);
+    bt3<QJ>(d, cc);
+}
+
+// The 3x3 block (rows 3QI.., columns 3QJ..) of V = B^T d B for one (tile, 2 channels): row by row - the column transform of
+// window row y, then its contribution B^T[i][y] to the three output rows (rows 0..4 feed QI = 0, rows 1..5 feed QI = 1).
+// (Two channels per item, not four: with 144 accumulator registers live the transform has ~70 registers to work in.)
+template <int QI, int QJ, int PW, int CKP, int PLANE>
+__device__ __forceinline__ void wino4_input_transform(const float* w, float* v) {
+    v2f o0[3], o1[3], o2[3], cc[3];
+    if constexpr (QI == 0) {
+        wino4_row<QJ, PW, CKP>(w, 0, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o0[j] = fK0 * cc[j];
+        wino4_row<QJ, PW, CKP>(w, 1, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o1[j] = -fAB2 * cc[j]; o2[j] = fAB2 * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 2, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] -= fK1 * cc[j]; o1[j] -= fB2 * cc[j]; o2[j] -= fB2 * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 3, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o1[j] += fA * cc[j]; o2[j] -= fA * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 4, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] += cc[j]; o1[j] += cc[j]; o2[j] += cc[j]; }
+    } else {
+        wino4_row<QJ, PW, CKP>(w, 1, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] = -fA2B * cc[j]; o1[j] = fA2B * cc[j]; o2[j] = fK0 * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 2, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] -= fA2 * cc[j]; o1[j] -= fA2 * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 3, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] += fB * cc[j]; o1[j] -= fB * cc[j]; o2[j] -= fK1 * cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 4, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] += cc[j]; o1[j] += cc[j]; }
+        wino4_row<QJ, PW, CKP>(w, 5, cc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o2[j] += cc[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        *reinterpret_cast<v2f*>(v + (0 * 6 + j) * PLANE) = o0[j];
+        *reinterpret_cast<v2f*>(v + (1 * 6 + j) * PLANE) = o1[j];
+        *reinterpret_cast<v2f*>(v + (2 * 6 + j) * PLANE) = o2[j];
+    }
+}
+}  // namespace
+
+// ---- host: U = G g G^T (6x6 per (cout, cin)), packed [cout/32][quadrant 4][chunk][ks 2][k 9][lane 64][4] -----------------
+size_t winograd4_pack_floats(int cin, int cout) { return (size_t)(cout / 32) * ((size_t)(cin / 8) * 36 * 256 + 4 * 4 * 256); }
+
+void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst) {
+    constexpr int CK = 16;
+    // G rows: p^k / N_p for the finite points, [0 0 1] for infinity; N_p = prod_{q != p} (p - q)
+    const double pts[5] = {0.0, kA, -kA, kB, -kB};
+    double G[6][3];
+    for (int j = 0; j < 5; ++j) {
+        double nrm = 1.0;
+        for (int l = 0; l < 5; ++l) if (l != j) nrm *= pts[j] - pts[l];
+        G[j][0] = 1.0 / nrm; G[j][1] = pts[j] / nrm; G[j][2] = pts[j] * pts[j] / nrm;
+    }
+    G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
+    std::vector<float> U((size_t)cout * cin * 36);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = oihw + ((size_t)co * cin + ci) * 9;
+            double t[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[kx] + G[i][1] * g[3 + kx] + G[i][2] * g[6 + kx];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    U[((size_t)co * cin + ci) * 36 + 6 * i + j] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+    size_t o = 0;
+    for (int cb = 0; cb < cout / 32; ++cb)
+        for (int q = 0; q < 4; ++q) {                       // quadrant (qi, qj): frequency rows 3qi..3qi+2, columns 3qj..3qj+2
+            const int qi = q >> 1, qj = q & 1;
+            for (int ch = 0; ch < cin / CK; ++ch)
+                for (int ks = 0; ks < CK / 8; ++ks)
+                    for (int k = 0; k < 9; ++k)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 4; ++j) {
+                                const int co = 32 * cb + (l & 31);
+                                const int ci = CK * ch + 8 * ks + 4 * (l >> 5) + j;
+                                const int xi = (3 * qi + k / 3) * 6 + 3 * qj + k % 3;
+                                dst[o++] = U[((size_t)co * cin + ci) * 36 + xi];
+                            }
+            for (int i = 0; i < 4 * 256; ++i) dst[o++] = 0.f;   // prefetch tail of this stream
+        }
+}
+
+template <int TW, int SRC>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
+    constexpr int CK = 16, CKP = CK + 4, PPP = CK / 4, NT_ = 512;
+    constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
+    constexpr int TH = 4 * TR;
+    constexpr int PH = TH + 2, PW = TW + 2;
+    constexpr int ITEMS = PH * PW * PPP;
+    constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
+    constexpr bool UP2 = SRC == SRC_UPCAT;
+    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
+    constexpr int LITEMS = LH * LW * PPP;
+    constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
+    constexpr int NRAW = (UP2 && NITL > NIT) ? NITL : NIT;
+    constexpr int KSC = CK / 8;                        // k-steps per chunk
+    constexpr int PAIRS = 9 * KSC;                     // (k-step, frequency) pairs per chunk and wave, 4 MFMAs each
+    constexpr int PF = 3;                              // B fragments in flight (must divide PAIRS: slots line up across chunks)
+    constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
+    static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
+    static_assert(PAIRS % PF == 0 && 16 * (CK / 2) * 4 == NT_ && 16 % TC == 0, "two (tile, 2-channel, quadrant) transform items per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const patch = smem;                             // [PH][PW][CKP]
+    float* const V = smem + PH * PW * CKP;                 // [36][32 tiles][CKP]
+    float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][CKP] low-res source region
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wid >> 1, cg = wid & 1;                  // frequency quadrant, 32-channel group of this wave
+    const int qi = q >> 1, qj = q & 1;
+    const int hh = lane >> 5, li = lane & 31;
+
+    // XCD-aware decode: the channel groups of one spatial tile run back to back on the same XCD (blocks b and b + 8 share
+    // an XCD under round-robin placement - speed only), so the patch they all read is fetched into that L2 once.
+    const int ny = a.Cout >> 6;
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * ny), rem = bid % (8 * ny);
+    const int cby = rem >> 3;                              // this workgroup's 64-channel block
+    int bt = grp * 8 + (rem & 7);                          // spatial tile index
+    if (bt >= a.tilesX * a.tilesY * a.N) return;
+    const int tx0 = (bt % a.tilesX) * TW;
+    bt /= a.tilesX;
+    const int ty0 = (bt % a.tilesY) * TH;
+    const int n = bt / a.tilesY;
+    if (a.tact != nullptr && a.tact[n] > 0.5f) return;
+    const int cb = cby * 2 + cg;                           // this wave's 32-channel block
+    const int nchunks = a.Cin / CK;
+
+    const int Hs = a.H >> 1, Ws = a.W >> 1;
+    const int ylo = UP2 ? (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)) : 0;
+    const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
+    const int nskip = UP2 ? a.Cskip / CK : 0;              // leading chunks that come straight from the skip tensor
+
+    float4 raw[NRAW];
+    auto issue = [&](int c) {
+        if (UP2 && c >= nskip) {                           // low-res region of an upsampled chunk
+            const int Cup = a.Cin - a.Cskip;
+            const float* base = a.src1 + (size_t)n * Hs * Ws * Cup + (c * CK - a.Cskip);
+#pragma unroll
+            for (int k = 0; k < NITL; ++k) {
+                const int idx = tid + k * NT_;
+                const int part = idx % PPP, pp = idx / PPP;
+                const int sy = ylo + pp / LW, sx = xlo + pp % LW;
+                if (idx < LITEMS && sy < Hs && sx < Ws)
+                    raw[k] = *reinterpret_cast<const float4*>(base + ((size_t)sy * Ws + sx) * Cup + part * 4);
+            }
+            return;
+        }
+        const int cs = UP2 ? a.Cskip : a.Cin;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * NT_;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PW, px = pp % PW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                raw[k] = *reinterpret_cast<const float4*>(a.src0 + (((size_t)n * a.H + gy) * a.W + gx) * cs + c * CK + part * 4);
+        }
+    };
+    auto commit = [&](int c) {
+        if (UP2 && c >= nskip) {
+            // park the low-res region in LDS, then interpolate the patch from it (ATen upsample_bilinear2d,
+            // align_corners=True: src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
+#pragma unroll
+            for (int k = 0; k < NITL; ++k) {
+                const int idx = tid + k * NT_;
+                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKP + (idx % PPP) * 4]) = raw[k];
+            }
+            __syncthreads();
+#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * NT_;
+                const int part = idx % PPP, pp = idx / PPP;
+                const int py = pp / PW, px = pp % PW;
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                if (idx < ITEMS) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                        const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
+                        const int y0 = (int)sy, x0 = (int)sx;
+                        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                        const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+                        const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * CKP + part * 4];
+                        const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * CKP + part * 4];
+                        v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * CKP), *reinterpret_cast<const float4*>(r0 + x1 * CKP),
+                                    *reinterpret_cast<const float4*>(r1 + x0 * CKP), *reinterpret_cast<const float4*>(r1 + x1 * CKP),
+                                    1.f - lx, lx, 1.f - ly, ly);
+                    }
+                    *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * NT_;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PW, px = pp % PW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = raw[k];
+                *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+            }
+        }
+    };
+    issue(0);
+
+    // this thread's two transform items: tiles tq and tq + 16 of the workgroup's 32 tiles (TC per row), channels
+    // [2*hc, 2*hc+2), quadrant q (the quadrant its own wave pair consumes: tid / 128 == wid / 2).  Eight lanes cover a tile's
+    // 16 channels and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart: all 64 banks, conflict-free.
+    const int t7 = tid & 127;
+    const int hc = t7 & 7, tq = t7 >> 3;
+    const int win = ((4 * (tq / TC)) * PW + 4 * (tq % TC)) * CKP + 2 * hc;     // top-left of tile tq's 6x6 input window
+    constexpr int WIN16 = (4 * (16 / TC)) * PW * CKP;                          // ... of tile tq + 16: 16 / TC tile rows further down
+    const int vout = ((3 * qi) * 6 + 3 * qj) * PLANE + tq * CKP + 2 * hc;      // plane (3qi, 3qj) of item 0
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    const size_t stream = (size_t)nchunks * PAIRS * 64 + 4 * 64;                   // float4 per (cb, quadrant) stream
+    const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + ((size_t)cb * 4 + q) * stream + lane;
+    float4 bq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
+    const int aoff = ((3 * qi) * 6 + 3 * qj) * PLANE + li * CKP + 4 * hh;          // this lane's row of V[(3qi, 3qj)]
+
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
+        commit(c);
+        __syncthreads();
+
+        // ---- input transform V = B^T d B, rows 3qi..3qi+2 and columns 3qj..3qj+2 (wave-uniform quadrant) --------------------
+        __builtin_amdgcn_sched_barrier(0);                 // keep the next chunk's loads (20 registers) behind the transform
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+            const float* wsrc = patch + win + it * WIN16;
+            float* vdst = V + vout + it * 16 * CKP;
+            switch (q) {
+                case 0: wino4_input_transform<0, 0, PW, CKP, PLANE>(wsrc, vdst); break;
+                case 1: wino4_input_transform<0, 1, PW, CKP, PLANE>(wsrc, vdst); break;
+                case 2: wino4_input_transform<1, 0, PW, CKP, PLANE>(wsrc, vdst); break;
+                default: wino4_input_transform<1, 1, PW, CKP, PLANE>(wsrc, vdst); break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunks) issue(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
+        __syncthreads();
+
+        // ---- 9 GEMMs per wave: pair p = (k-step, k); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair -----
+        const float4* bp = bptr + (size_t)c * PAIRS * 64;
+        float4 a0 = *reinterpret_cast<const float4*>(&V[aoff]);
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+            float4 a1;
+            if (p + 1 < PAIRS) {
+                const int ks1 = (p + 1) / 9, k1 = (p + 1) % 9;
+                a1 = *reinterpret_cast<const float4*>(&V[((k1 / 3) * 6 + k1 % 3) * PLANE + aoff + 8 * ks1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int k = p % 9;
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq[p % PF].x, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq[p % PF].y, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq[p % PF].z, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq[p % PF].w, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
+            if (p + 1 < PAIRS) a0 = a1;
+        }
+    }
+
+    // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1].
+    // Wave (qi, qj) holds M[3qi..3qi+2][3qj..3qj+2] and forms its partial tile  Yp = A^T[:, 3qi..] M_q A[3qj.., :]  (lane-local).
+    // Four rounds of 4 accumulator registers (8 tiles): partials -> P[cg][q][rr][16 outputs][64 lanes] in LDS, barrier, then
+    // thread (cg, rr, hh, 2x2 window, 4 channels) sums the four quadrants in the order q = 0..3 and finishes the pixels.
+    float* const P = smem;
+    constexpr int V4 = 8;                                   // float4 per 32-channel group
+    const int r_c4 = tid & 7, r_cg = (tid >> 3) & 1, r_hh = (tid >> 4) & 1, r_w = (tid >> 5) & 3, r_rr = tid >> 7;
+    const int cout0 = cby * 64 + r_cg * 32 + 4 * r_c4;
+    const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + cout0);
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    // one-dimensional partial output transform of three values (the quadrant's rows or columns) into four
+    auto at4 = [&](int g, float m0, float m1, float m2, float* t) {
+        if (g == 0) {            // frequencies 0, a, -a
+            const float s = m1 + m2, d = m1 - m2;
+            t[0] = m0 + s; t[1] = fA * d; t[2] = fA2 * s; t[3] = fA3 * d;
+        } else {                 // frequencies b, -b, inf
+            const float s = m0 + m1, d = m0 - m1;
+            t[0] = s; t[1] = fB * d; t[2] = fB2 * s; t[3] = fmaf(fB3, d, m2);
+        }
+    };
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        __syncthreads();                                   // V (first round) / the previous round's partials are no longer read
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float t[3][4];                                 // [kj][a']: rows transformed, per frequency column of the quadrant
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) {
+                float m0, m1, m2;
+                // accumulator register 4g + rr with a compile-time index per round
+                switch (g) {
+                    case 0: m0 = acc[0 + kj][0 + rr]; m1 = acc[3 + kj][0 + rr]; m2 = acc[6 + kj][0 + rr]; break;
+                    case 1: m0 = acc[0 + kj][4 + rr]; m1 = acc[3 + kj][4 + rr]; m2 = acc[6 + kj][4 + rr]; break;
+                    case 2: m0 = acc[0 + kj][8 + rr]; m1 = acc[3 + kj][8 + rr]; m2 = acc[6 + kj][8 + rr]; break;
+                    default: m0 = acc[0 + kj][12 + rr]; m1 = acc[3 + kj][12 + rr]; m2 = acc[6 + kj][12 + rr]; break;
+                }
+                at4(qi, m0, m1, m2, t[kj]);
+            }
+            float* pw = P + ((((cg * 4 + q) * 4 + rr) * 16) * 64) + lane;
+#pragma unroll
+            for (int ay = 0; ay < 4; ++ay) {
+                float y[4];
+                at4(qj, t[0][ay], t[1][ay], t[2][ay], y);
+#pragma unroll
+                for (int bx = 0; bx < 4; ++bx) pw[(ay * 4 + bx) * 64] = y[bx];
+            }
+        }
+        __syncthreads();
+        // reduce + finish: tile t = rr + 8g + 4hh of the M-block, window (wy, wx) of its 4x4 pixels
+        {
+            const int t = r_rr + 8 * g + 4 * r_hh;
+            const int py = 4 * (t / TC) + 2 * (r_w >> 1), px = 4 * (t % TC) + 2 * (r_w & 1);
+            const float* pr = P + (((r_cg * 4) * 4 + r_rr) * 16) * 64 + r_hh * 32 + 4 * r_c4;
+            float4 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int oidx = (2 * (r_w >> 1) + (e >> 1)) * 4 + 2 * (r_w & 1) + (e & 1);
+                float4 s = *reinterpret_cast<const float4*>(pr + oidx * 64);
+#pragma unroll
+                for (int qq = 1; qq < 4; ++qq) s = f4add(s, *reinterpret_cast<const float4*>(pr + (qq * 4 * 16 + oidx) * 64));
+                s = f4add(s, bias4);
+                o[e] = make_float4(fmaxf(s.x, kLeaky * s.x), fmaxf(s.y, kLeaky * s.y), fmaxf(s.z, kLeaky * s.z), fmaxf(s.w, kLeaky * s.w));
+                const int gy = ty0 + py + (e >> 1), gx = tx0 + px + (e & 1);
+                if (gy < a.H && gx < a.W)
+                    *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cout0) = o[e];
+            }
+            if (a.pooled != nullptr) {                     // MaxPool2d(2) of this window for the next stage (noise.py:22-25)
+                const int gy = (ty0 + py) >> 1, gx = (tx0 + px) >> 1;
+                if (gy < Hp && gx < Wp)
+                    *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * a.Cout + cout0) =
+                        f4max(f4max(o[0], o[1]), f4max(o[2], o[3]));
+            }
+        }
+    }
+    (void)V4;
+}
+
+template <int TW, int SRC>
+static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
+    constexpr int CKP = 20, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
+    constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 36 * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * CKP * sizeof(float);
+    constexpr size_t lds_out = (size_t)2 * 4 * 4 * 16 * 64 * sizeof(float);
+    constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    auto kern = conv3x3_wino4_kernel<TW, SRC>;
+    static DeviceOnce cap;
+    if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
+    const int ntiles = p.tiles_x * p.tiles_y * a.N, ny = a.Cout / 64;
+    dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * ny));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// `a.wpack` must be the F(4x4) pack (pack_winograd4_weights).
+hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
+    if (!p.use || p.algo != 4 || a0.Cout % 64 || a0.Cin % 16 || (src_mode == SRC_UPCAT && a0.Cskip % 16)) return hipErrorInvalidValue;
+    ConvArgs a = a0;
+    a.tilesX = p.tiles_x;
+    a.tilesY = p.tiles_y;
+    if (p.tw == 32) {
+        if (src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN>(a, p, s);
+        if (src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT>(a, p, s);
+    } else if (p.tw == 16) {
+        if (src_mode == SRC_PLAIN) return launch_wino4_inst<16, SRC_PLAIN>(a, p, s);
+        if (src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT>(a, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pnp

@@ -70,10 +70,27 @@ void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* 
 // Eligibility + tile plan.  The transforms and the 16-accumulator epilogue are per-item overhead that long K amortises
 // best (1.65x over the direct kernel at Cin >= 128), but even the K = 288 layers gain ~9 %; small problems (too few
 // workgroups) stay on the direct kernel with split-K.
-WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, const Tuning& t) {
+WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t) {
     WinoPlan p{};
     p.use = false;
+    p.algo = 1;
     if (t.no_wino || Cin < t.wino_min_cin || Cin % 32 || Cout % 32) return p;
+    // F(4x4,3x3) (winograd4_kernels.hip): 1.78x fewer MFMAs again where the matrix pipe is the bound - long K (Cin >= 128),
+    // 64-channel output blocks, 32 tiles of 4x4 pixels per workgroup (16 x 32 or 32 x 16 pixels), so the image must be at
+    // least that large in the tile's long direction or half the work is padding (the 16 x 16 bottom level stays on F(2x2)).
+    if (!t.no_f4 && Cin >= t.f4_min_cin && Cout % 64 == 0 && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
+        W >= 16 && H >= 16 && (W >= 32 || H >= 32)) {
+        WinoPlan f{};
+        f.algo = 4;
+        f.tw = W >= 32 ? 32 : 16;
+        f.th = f.tw == 32 ? 16 : 32;
+        f.bn = 64; f.wm = 1; f.wn = 2; f.ck = 16;
+        f.tiles_x = (W + f.tw - 1) / f.tw;
+        f.tiles_y = (H + f.th - 1) / f.th;
+        const long blocks = (long)f.tiles_x * f.tiles_y * N * (Cout / f.bn);
+        f.use = blocks >= t.wino_min_blocks;
+        if (f.use) return f;
+    }
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     // Cout >= 128: one 8-wave workgroup per CU (32 tiles x 128 channels, 32-channel chunks).  Cout = 64 / 32: 4-wave
     // workgroups (32 tiles x 64 channels / 64 tiles x 32 channels) small enough for TWO per CU, so one workgroup's

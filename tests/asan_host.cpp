@@ -29,7 +29,7 @@ int main() {
             for (int li = 1; li < N_LAYERS - 1; ++li) {
                 const LayerSpec& L = kLayers[li];
                 const int n = sh[0], h = sh[1] >> L.level, wd = sh[2] >> L.level;
-                const WinoPlan wp = winograd_plan(n, h, wd, L.cin, L.cout, t);
+                const WinoPlan wp = winograd_plan(n, h, wd, L.cin, L.cout, L.src == SRC_POOL ? (int)SRC_PLAIN : L.src, t);
                 const ConvPlan cp = conv3x3_plan(n, h, wd, L.cin, L.cout, false);
                 const ConvPlan cb = conv3x3_plan(n, h, wd, L.cin, L.cout, true);
                 CHECK(cp.tiles_x * cp.tw >= wd && cp.tiles_y * cp.th >= h && cp.splitk >= 1);
@@ -41,9 +41,10 @@ int main() {
                 for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
                 if (wp.use) {
                     CHECK(wp.tiles_x * wp.tw >= wd && wp.tiles_y * wp.th >= h && L.cin % wp.ck == 0);
-                    const size_t pf = winograd_pack_floats(L.cin, L.cout);
+                    const size_t pf = wp.algo == 4 ? winograd4_pack_floats(L.cin, L.cout) : winograd_pack_floats(L.cin, L.cout);
                     float* dst = (float*)std::malloc(pf * sizeof(float));          // exact size: redzones right behind it
-                    pack_winograd_weights(w.data(), L.cin, L.cout, wp.ck, dst);
+                    if (wp.algo == 4) pack_winograd4_weights(w.data(), L.cin, L.cout, dst);
+                    else pack_winograd_weights(w.data(), L.cin, L.cout, wp.ck, dst);
                     std::free(dst);
                     ++packed_layers;
                 }

@@ -273,7 +273,7 @@ def test_cli_eval_on_a_directory_of_mat_files(tmp_path):
     d = tmp_path / "set_4_10"
     d.mkdir()
     for i in range(3):
-        D.save_mat(str(d / f"img{i}_4_10.mat"), p, i)
+        D.save_mat(str(d / ("img_" + "abc"[i] + "_4_10.mat")), p, i)      # the task regex takes the FIRST <digits>_<digits> of the name
     out = cli.main(["--block_size", "18", "--n_embeds", "9", "--data", str(d), "--limit", "0", "eval", "--rtg", "10",
                     "--max_timesteps", "6"])
     assert len(out) == 1 and out[0]["n"] == 3 and out[0]["set"] == str(d)

@@ -163,9 +163,10 @@ def test_winograd_path_matches_oracle_per_stage(sd_np, n, h, w, monkeypatch):
     and odd-sized problems - 3x4-pixel bottom level, 8/16/32-wide tile variants - run it too), per stage against the oracle."""
     if n < 64:
         monkeypatch.setenv("PNP_WINO_MIN_BLOCKS", "1")
+    monkeypatch.setenv("PNP_NO_WINO_F4", "1")              # this test is about the F(2x2) kernel; F(4x4) has its own below
     e = _engine(n, h, w, sd_np, keep_stages=True)
     algos = e.conv_algorithms()
-    assert sum(1 for v in algos if v == 1) >= (20 if n == 64 else 26)
+    assert sum(1 for v in algos if v == 1) >= (20 if n == 64 else 26) and 4 not in algos
     sd = O.torch_weights(sd_np)
     x = (torch.from_numpy(synthetic.hash_uniform(9, h * 100 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
     sigma = torch.linspace(5, 50, n) / 255.0
@@ -176,6 +177,31 @@ def test_winograd_path_matches_oracle_per_stage(sd_np, n, h, w, monkeypatch):
         a = e.read_stage(which).cpu()
         err = float((a - ref).abs().max())
         # FLOAT TOLERANCE: Winograd F(2x2,3x3) in f32: same order of error as the direct sum (K up to 6912 terms)
+        assert err < 5e-5 * max(1.0, float(ref.abs().max())), f"stage {name}: max err {err}"
+    np.testing.assert_allclose(got.cpu().numpy(), torch.clamp(ref_raw, 0, 1).numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,h,w,min_cin", [(2, 128, 128, 128), (2, 96, 112, 128), (1, 144, 64, 128), (1, 256, 256, 128), (3, 128, 64, 64)])
+def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, monkeypatch):
+    """F(4x4,3x3) (winograd4_kernels.hip, points 0, +-3/4, +-3/2, inf) on every layer it can take - workgroup gate lifted so
+    small and ragged sizes run it (partial 4x4 tiles, 16- and 32-wide tile variants, upsample+concat sources, pooled copies
+    written by its epilogue) - per stage against the oracle.  min_cin = 64 also sends the 64-channel layers through it."""
+    monkeypatch.setenv("PNP_WINO_MIN_BLOCKS", "1")
+    monkeypatch.setenv("PNP_WINO_F4_MIN_CIN", str(min_cin))
+    e = _engine(n, h, w, sd_np, keep_stages=True)
+    algos = e.conv_algorithms()
+    assert sum(1 for v in algos if v == 4) >= (9 if min_cin == 64 else 1), algos
+    sd = O.torch_weights(sd_np)
+    x = (torch.from_numpy(synthetic.hash_uniform(19, h * 100 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
+    sigma = torch.linspace(5, 50, n) / 255.0
+    got = e.denoise(x.cuda(), sigma.cuda())
+    noise_map = torch.ones(n, 1, h, w) * sigma.view(n, 1, 1, 1)
+    ref_raw, stages = O.unet_forward(sd, torch.cat([x, noise_map], 1), return_stages=True)
+    for which, (name, ref) in enumerate(stages.items()):
+        a = e.read_stage(which).cpu()
+        err = float((a - ref).abs().max())
+        # FLOAT TOLERANCE: F(4x4,3x3) in f32 with the 3/4, 3/2 points: ~2e-6 of the output scale per layer (3x F(2x2), 6x the
+        # direct sum; winograd4_kernels.hip header), accumulated over the up to 9 F(4x4) layers in front of a stage
         assert err < 5e-5 * max(1.0, float(ref.abs().max())), f"stage {name}: max err {err}"
     np.testing.assert_allclose(got.cpu().numpy(), torch.clamp(ref_raw, 0, 1).numpy(), rtol=0, atol=1e-5)
 
@@ -250,7 +276,7 @@ def test_denoiser_shape_sweep(sd_np, n, h, w, mode, monkeypatch):
     e.load_weights(sd_np)
     algos = e.conv_algorithms()[1:27]
     if mode == "winograd":
-        assert any(v == 1 for v in algos)
+        assert any(v in (1, 4) for v in algos)
     if mode in ("direct", "bf16"):
         assert all(v == 0 for v in algos)
     sd = O.torch_weights(sd_np)
