@@ -16,7 +16,7 @@ struct Tuning {
     bool wino_big = false;        // PNP_WINO_BIG_GROUPS: the 8-wave plans everywhere
     bool wino_small = false;      // PNP_WINO_SMALL_GROUPS
     bool no_wino = false;         // PNP_NO_WINOGRAD
-    int f4_min_cin = 128;         // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
+    int f4_min_cin = 64;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
 };
 Tuning tuning_from_env();

@@ -75,7 +75,7 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
     p.use = false;
     p.algo = 1;
     if (t.no_wino || Cin < t.wino_min_cin || Cin % 32 || Cout % 32) return p;
-    // F(4x4,3x3) (winograd4_kernels.hip): 1.78x fewer MFMAs again where the matrix pipe is the bound - long K (Cin >= 128),
+    // F(4x4,3x3) (winograd4_kernels.hip): 1.78x fewer MFMAs again where the matrix pipe is the bound - Cin >= 64 (measured: +10 % at 64, +21..30 % at 128..768),
     // 64-channel output blocks, 32 tiles of 4x4 pixels per workgroup (16 x 32 or 32 x 16 pixels), so the image must be at
     // least that large in the tile's long direction or half the work is padding (the 16 x 16 bottom level stays on F(2x2)).
     if (!t.no_f4 && Cin >= t.f4_min_cin && Cout % 64 == 0 && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
