@@ -4,6 +4,10 @@
     python -m dt4image_restoration_amd.cli --block_size 18 --n_embeds 9 mcts --rtg 5  --max_timesteps 30
     python -m dt4image_restoration_amd.cli --block_size 18 --n_embeds 6 flex --max_timesteps 30
 
+Multi-GPU (BASELINE configs[2]): launch the same command under `python -m torch.distributed.run --nproc-per-node N
+--master-addr 127.0.0.1 -m dt4image_restoration_amd.cli ... eval ...`: every rank takes a contiguous shard of each set's
+images (drivers/sharded.py), the per-image PSNR / stop iteration are gathered over RCCL, rank 0 prints.
+
 Differences: `train` is out of scope; checkpoint and data locations are options instead of
 hard-coded paths (main.py:175,178,181-183); without `--data` the run uses the seeded synthetic problems and without
 `--denoiser-ckpt` / `--policy-ckpt` the seeded stand-in weights (the real ones are external downloads); images of one
@@ -13,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import sys
 
 import numpy as np
@@ -34,17 +39,28 @@ def _build(args, mode):
     return model, PnPEnv(max_episode_step=30, denoiser=den, device_type="cuda", no_ref_scorer=None), scorer
 
 
-def _batches(args, flex_target=None):
+def _sets(args, flex_target=None):
+    """(name, number of images, load(start, stop) -> (batch dict, task tokens)) per evaluation set."""
     from . import data as D, synthetic
     if args.data:
         for d in args.data:
-            batch, tasks = D.load_dir(d, limit=args.limit)
-            yield d, batch, D.task_tokens(tasks, flex_target)
+            def load(a, b, d=d):
+                batch, tasks = D.load_dir(d, limit=args.limit, start=a, stop=b)
+                return batch, D.task_tokens(tasks, flex_target)
+            yield d, len(D.list_dir(d, args.limit)), load
     else:
         for accel, sig in ((4, 10), (8, 10)):
-            p = synthetic.make_problem(args.limit or 7, args.size, args.size, accel=accel, sigma_n=sig / 255.0, seed=args.seed + accel)
-            tasks = [f"{accel}x_{sig}"] * p["gt"].shape[0]
-            yield f"synthetic {accel}x_{sig}", p, D.task_tokens(tasks, flex_target)
+            def load(a, b, accel=accel, sig=sig):
+                p = synthetic.make_problem(b - a, args.size, args.size, accel=accel, sigma_n=sig / 255.0, seed=args.seed + accel,
+                                           first_slice=a)
+                return p, D.task_tokens([f"{accel}x_{sig}"] * (b - a), flex_target)
+            yield f"synthetic {accel}x_{sig}", args.limit or 7, load
+
+
+def _batches(args, flex_target=None):
+    for name, total, load in _sets(args, flex_target):
+        batch, tokens = load(0, total)
+        yield name, batch, tokens
 
 
 def main(argv=None):
@@ -70,24 +86,47 @@ def main(argv=None):
     from . import data as D
     from .drivers.greedy import GreedyEvaluator
     from .drivers.mcts import MCTS
+    from .drivers.sharded import run_sharded_greedy
     out = []
-    if args.mode in ("eval", "mcts"):
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:                                            # one process per GPU under torch.distributed.run
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        if args.mode != "eval":
+            raise SystemExit("multi-GPU launch is implemented for `eval` (slices shard; one tree search needs one GPU)")
+    if args.mode == "eval":
+        model, env, _ = _build(args, "norm")
+        ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size,
+                             device_type=torch.device("cuda", torch.cuda.current_device()), sync_every=5)
+        for name, total, load in _sets(args):
+            def load_shard(a, b, load=load):
+                batch, tokens = load(a, b)
+                mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
+                return mat, torch.full((b - a,), D.normalised_rtg(args.rtg)), torch.from_numpy(tokens)
+            r = run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize)
+            out.append({"set": name, "n": total, "psnr": float(r.reward.mean()),
+                        "psnr_increment": float((r.reward - r.initial_reward).mean()),
+                        "mean_stop_iteration": float(r.stop_time.float().mean()), "ranks": world})
+            if rank == 0:
+                print(json.dumps(out[-1]), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return out
+    if args.mode == "mcts":
         model, env, scorer = _build(args, "norm")
         ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size)
         for name, batch, tokens in _batches(args):
             mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
             n = mat["gt"].shape[0]
             rtg = torch.full((n,), D.normalised_rtg(args.rtg))
-            first = mat.get("x0_raw")               # datasets.py:162: the policy's first token is the UNclipped Re x0
-            if args.mode == "eval":
-                r = ev.run(mat, rtg, torch.from_numpy(tokens), first_state=first)
-                out.append({"set": name, "n": n, "psnr": float(r.reward.mean()), "psnr_increment": float((r.reward - r.initial_reward).mean()),
-                            "mean_stop_iteration": float(r.stop_time.float().mean())})
-            else:
-                tree = MCTS(ev, scorer, rounds=args.rollouts, seed=args.seed)
-                rewards = [float(tree.run({k: (v[i:i + 1] if k != "mask" else v) for k, v in mat.items()}, rtg[i:i + 1],
-                                          torch.from_numpy(tokens[i:i + 1]))[0]) for i in range(n)]
-                out.append({"set": name, "n": n, "mcts_psnr": float(np.mean(rewards))})
+            # all images of the set are searched at once: one tree per image, children and rollouts batched over images;
+            # the policy's first token is the UNclipped Re x0 (datasets.py:162)
+            tree = MCTS(ev, scorer, rounds=args.rollouts, seed=args.seed)
+            psnr, _ = tree.run_batch(mat, rtg, torch.from_numpy(tokens), first_state=mat.get("x0_raw"))
+            out.append({"set": name, "n": n, "mcts_psnr": float(psnr.mean()),
+                        "rollouts_per_s": round(tree.last_stats["rollouts_per_s"], 2)})
             print(json.dumps(out[-1]), flush=True)
     else:
         model, env, _ = _build(args, "flex")

@@ -56,14 +56,23 @@ def load_mat(path: str) -> Dict[str, np.ndarray]:
     return out
 
 
-def load_dir(data_dir: str, limit: int = 0) -> Tuple[Dict[str, np.ndarray], List[str]]:
-    """All `.mat` files of a directory (sorted, datasets.py:146-147) stacked into one batch dict
-    {x0,y0,ATy0: [N,1,H,W,2], mask [H,W], gt [N,1,H,W], x0_raw [N,1,H,W]} + their task names."""
+def list_dir(data_dir: str, limit: int = 0) -> List[str]:
+    """The `.mat` files of a directory in the reference's order (sorted, datasets.py:146-147), first `limit` if given."""
     fns = sorted(f for f in os.listdir(data_dir) if f.endswith(".mat"))
     if limit:
         fns = fns[:limit]
     if not fns:
         raise FileNotFoundError(f"no .mat files in {data_dir}")
+    return fns
+
+
+def load_dir(data_dir: str, limit: int = 0, start: int = 0, stop: int = None) -> Tuple[Dict[str, np.ndarray], List[str]]:
+    """The `.mat` files [start, stop) of a directory (of its first `limit` files, sorted) stacked into one batch dict
+    {x0,y0,ATy0: [N,1,H,W,2], mask [H,W], gt [N,1,H,W], x0_raw [N,1,H,W]} + their task names.  A rank of a sharded run
+    reads only its own files."""
+    fns = list_dir(data_dir, limit)[start:stop]
+    if not fns:
+        raise FileNotFoundError(f"no .mat files in {data_dir} [{start}:{stop}]")
     items = [load_mat(os.path.join(data_dir, f)) for f in fns]
     h, w = items[0]["mask"].shape[-2:]
     for f, it in zip(fns, items):

@@ -13,6 +13,14 @@ checkpoint trained for the reference produces the same action sequence here:
   * time < ctx: window = steps [0, ctx); action read at position `time`, rtg at position `time`  (eval.py:150-166)
   * time >= ctx: window = steps [time-ctx, time) - it EXCLUDES the step just observed; action read at the last
     position, rtg at the second-to-last                                                           (eval.py:168-184,53-60)
+
+Policy-side cost (the reference re-encodes the whole 6-image context window in BOTH forwards of every step): the state
+encoder is a pure per-image function, so each observation is encoded ONCE when it is written into the context
+(`PolicyContext.ee`) and both forwards read the cached embeddings - 1 encoder image per slice and step instead of 12.
+`sync_every` spaces out the only host synchronisation of the loop (the all-stopped check).
+
+`rollout_rows` is the same loop with a per-row clock (rows of one batch at different episode times), which is what a
+batched tree search needs: the nodes selected in different images sit at different depths.
 """
 from __future__ import annotations
 
@@ -34,50 +42,36 @@ class GreedyResult:
     x: torch.Tensor             # [N,1,H,W] final images (device)
 
 
+@dataclass
+class PolicyContext:
+    """Context buffers of the policy (eval.py:65-70) for n rows."""
+    es: torch.Tensor            # [n, T, 16384] observations
+    ea: torch.Tensor            # [n, T, 3] actions (model order)
+    er: torch.Tensor            # [n, T, 1] return-to-go tokens
+    et: torch.Tensor            # [n, T, 1] time steps
+    ek: torch.Tensor            # [n, T] task token
+    ee: Optional[torch.Tensor]  # [n, T, E] cached state-encoder outputs of `es` (None: re-encode like the reference)
+
+    def window(self, lo: int, hi: int):
+        return (self.er[:, lo:hi], self.es[:, lo:hi], self.et[:, lo:hi], self.ek[:, lo:hi], self.ea[:, lo:hi],
+                None if self.ee is None else self.ee[:, lo:hi])
+
+
 class GreedyEvaluator:
     def __init__(self, model, env, action_dim: int = 3, max_timesteps: int = 30, block_size: int = 18,
-                 device_type="cuda"):
+                 device_type="cuda", cache_state_embeddings: bool = True, sync_every: int = 1):
         self.model = model.to(device_type).eval()
         self.env = env
         self.action_dim = action_dim
         self.max_timesteps = max_timesteps
         self.context_length = block_size // 3
         self.device = torch.device(device_type)
+        self.cache_state_embeddings = cache_state_embeddings
+        self.sync_every = max(1, int(sync_every))
 
-    # ---- policy calls --------------------------------------------------------------------------------------
-    def _pick(self, action_dict, pred_actions, pos: int):
-        picked = OrderedDict((k, v[:, pos, 0].contiguous()) for k, v in action_dict.items())     # each [N]
-        return picked, pred_actions[:, pos]
-
+    # ---- context ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def _initial(self, es, ea, er, et, ek):
-        ctx = self.context_length
-        pred_actions, action_dict = self.model(er[:, :ctx], es[:, :ctx], et[:, :ctx], ek[:, :ctx], actions=None)
-        action, pa = self._pick(action_dict, pred_actions, 0)
-        ea[:, 0] = pa
-        # eval.py:90-95 hands the model the rtg/action at INDEX ctx - still all zeros at this point - which the model
-        # broadcasts over every position of the window
-        w = min(ctx, es.shape[1])
-        zeros_r = torch.zeros_like(er[:, :w])
-        zeros_a = torch.zeros_like(ea[:, :w])
-        pred_rtg = self.model(zeros_r, es[:, :ctx], et[:, :ctx], ek[:, :ctx], zeros_a, eval_rtg=True)
-        return action, pred_rtg[:, 0]
-
-    @torch.no_grad()
-    def _predict(self, es, ea, er, et, ek, time: int):
-        ctx = self.context_length
-        lo, hi = (0, ctx) if time < ctx else (time - ctx, time)
-        pa_pos = time if time < ctx else -1
-        rtg_pos = time if time + 1 <= ctx else -2
-        pred_actions, action_dict = self.model(er[:, lo:hi], es[:, lo:hi], et[:, lo:hi], ek[:, lo:hi], ea[:, lo:hi],
-                                               eval_actions=True)
-        action, pa = self._pick(action_dict, pred_actions, pa_pos)
-        ea[:, time] = pa
-        pred_rtg = self.model(er[:, lo:hi], es[:, lo:hi], et[:, lo:hi], ek[:, lo:hi], ea[:, lo:hi], eval_rtg=True)
-        return action, pred_rtg[:, rtg_pos]
-
-    # ---- rollout ---------------------------------------------------------------------------------------------
-    def buffers(self, n: int, task: torch.Tensor):
+    def buffers(self, n: int, task: torch.Tensor) -> PolicyContext:
         """Zeroed context buffers (eval.py:65-70): states [n,T,16384], actions [n,T,3], rtg [n,T,1], timesteps, task."""
         dev, T = self.device, self.max_timesteps
         es = torch.zeros((n, T, 128 * 128), device=dev)
@@ -85,9 +79,97 @@ class GreedyEvaluator:
         er = torch.zeros((n, T, 1), device=dev)
         et = torch.arange(T, device=dev).reshape(1, T, 1).expand(n, -1, -1).contiguous()
         ek = task.reshape(n, 1).to(dev).expand(-1, T).contiguous()
-        return es, ea, er, et, ek
+        ee = None
+        if self.cache_state_embeddings:
+            z = self.model.encode_states(torch.zeros((1, 128 * 128), device=dev))      # a not-yet-observed (all-zero) state
+            ee = z.reshape(1, 1, -1).expand(n, T, -1).contiguous()
+        return PolicyContext(es, ea, er, et, ek, ee)
 
-    def rollout(self, states, action, pred_rtg, start_time: int, es, ea, er, et, ek, scorer=None):
+    @torch.no_grad()
+    def observe(self, ctx: PolicyContext, time, ob: torch.Tensor, rows: Optional[torch.Tensor] = None) -> None:
+        """Write observation `ob` [n,16384] at step `time` (int, or a per-row int64 tensor) for `rows` (bool mask or None)."""
+        emb = self.model.encode_states(ob) if ctx.ee is not None else None
+        if isinstance(time, int):
+            if rows is None:
+                ctx.es[:, time] = ob
+                if emb is not None:
+                    ctx.ee[:, time] = emb
+            else:
+                ctx.es[rows, time] = ob[rows]
+                if emb is not None:
+                    ctx.ee[rows, time] = emb[rows]
+            return
+        idx = torch.arange(ob.shape[0], device=ob.device)
+        if rows is not None:
+            idx, time, ob = idx[rows], time[rows], ob[rows]
+            emb = None if emb is None else emb[rows]
+        ctx.es[idx, time] = ob
+        if emb is not None:
+            ctx.ee[idx, time] = emb
+
+    # ---- policy calls --------------------------------------------------------------------------------------
+    def _pick(self, action_dict, pred_actions, pos: int):
+        picked = OrderedDict((k, v[:, pos, 0].contiguous()) for k, v in action_dict.items())     # each [N]
+        return picked, pred_actions[:, pos]
+
+    @torch.no_grad()
+    def _initial(self, ctx: PolicyContext):
+        c = self.context_length
+        er, es, et, ek, ea, ee = ctx.window(0, c)
+        pred_actions, action_dict = self.model(er, es, et, ek, actions=None, state_emb=ee)
+        action, pa = self._pick(action_dict, pred_actions, 0)
+        ctx.ea[:, 0] = pa
+        # eval.py:90-95 hands the model the rtg/action at INDEX ctx - still all zeros at this point - which the model
+        # broadcasts over every position of the window
+        pred_rtg = self.model(torch.zeros_like(er), es, et, ek, torch.zeros_like(ea), eval_rtg=True, state_emb=ee)
+        return action, pred_rtg[:, 0]
+
+    @torch.no_grad()
+    def _predict(self, ctx: PolicyContext, time: int):
+        c = self.context_length
+        lo, hi = (0, c) if time < c else (time - c, time)
+        pa_pos = time if time < c else -1
+        rtg_pos = time if time + 1 <= c else -2
+        er, es, et, ek, ea, ee = ctx.window(lo, hi)
+        pred_actions, action_dict = self.model(er, es, et, ek, ea, eval_actions=True, state_emb=ee)
+        action, pa = self._pick(action_dict, pred_actions, pa_pos)
+        ctx.ea[:, time] = pa                                   # inside the window only while time < ctx (a view: `ea` sees it)
+        pred_rtg = self.model(er, es, et, ek, ea, eval_rtg=True, state_emb=ee)
+        return action, pred_rtg[:, rtg_pos]
+
+    @torch.no_grad()
+    def _predict_rows(self, ctx: PolicyContext, tvec: torch.Tensor):
+        """`_predict` with a per-row time `tvec` [n] (int64, device): every row gets the window, read positions and write
+        position its own clock implies.  Rows whose clock has run past the last step are clamped (their result is unused)."""
+        c, T = self.context_length, self.max_timesteps
+        n = tvec.shape[0]
+        t = tvec.clamp(max=T - 1)
+        early = t < c
+        lo = torch.where(early, torch.zeros_like(t), t - c)
+        idx = lo[:, None] + torch.arange(c, device=t.device)[None, :]                      # [n, c] window steps
+        pos_a = torch.where(early, t, torch.full_like(t, c - 1))
+        pos_r = torch.where(early, t, torch.full_like(t, c - 2))
+        rows = torch.arange(n, device=t.device)
+
+        def win(buf):
+            if buf.dim() == 2:
+                return buf.gather(1, idx)
+            return buf.gather(1, idx[:, :, None].expand(-1, -1, buf.shape[2]))
+
+        er, et, ek = win(ctx.er), win(ctx.et), win(ctx.ek)
+        ee = win(ctx.ee) if ctx.ee is not None else None
+        es = win(ctx.es) if ctx.ee is None else ee              # with cached embeddings `states` is only read for its shape
+        ea = win(ctx.ea)
+        pred_actions, action_dict = self.model(er, es, et, ek, ea, eval_actions=True, state_emb=ee)
+        action = OrderedDict((k, v[rows, pos_a, 0].contiguous()) for k, v in action_dict.items())
+        pa = pred_actions[rows, pos_a]
+        ctx.ea[rows, t] = pa
+        ea = win(ctx.ea)                                        # the write is inside the window while t < ctx
+        pred_rtg = self.model(er, es, et, ek, ea, eval_rtg=True, state_emb=ee)
+        return action, pred_rtg[rows, pos_r]
+
+    # ---- rollout ---------------------------------------------------------------------------------------------
+    def rollout(self, states, action, pred_rtg, start_time: int, ctx: PolicyContext, scorer=None):
         """eval.py:189-220 from `start_time`: step, observe, re-plan, until every slice stopped or max_timesteps.
         Returns (reward [N,1] CPU, stop_time [N]).  `scorer(states) -> [N]` replaces PSNR (no-reference rollouts)."""
         dev, T = self.device, self.max_timesteps
@@ -99,16 +181,55 @@ class GreedyEvaluator:
             done = torch.as_tensor(done, device=dev).reshape(-1)
             stop_time[done & ~stopped] = time
             stopped |= done
-            if time == T or bool(stopped.all()):
+            if time == T:
+                break
+            if (time - start_time) % self.sync_every == 0 and bool(stopped.all()):      # the loop's only host sync
                 break
             live = ~stopped
-            ob = policy_observation(states["x"])
-            es[live, time] = ob[live]
-            er[live, time] = pred_rtg[live]
-            new_action, new_rtg = self._predict(es, ea, er, et, ek, time)
+            self.observe(ctx, time, policy_observation(states["x"]), live)
+            ctx.er[live, time] = pred_rtg[live]
+            new_action, new_rtg = self._predict(ctx, time)
             for k in action:                                   # stopped slices keep the action that stopped them
                 action[k] = torch.where(live, new_action[k], action[k])
             pred_rtg = torch.where(live.reshape(n, 1), new_rtg, pred_rtg)
+        if scorer is not None:
+            reward = torch.as_tensor(scorer(states)).reshape(n, 1).float().cpu()
+        else:
+            reward = self.env.compute_reward(states["x"], states["gt"])
+        return reward, stop_time.cpu()
+
+    def rollout_rows(self, states, action, pred_rtg, start_times: torch.Tensor, ctx: PolicyContext, scorer=None,
+                     active: Optional[torch.Tensor] = None):
+        """`rollout` with a per-row clock: row i takes its first step at time start_times[i] (>= 1) and runs until it stops
+        or its clock passes max_timesteps.  `active` [N] bool: rows that take part at all (others are never stepped).
+        Returns (reward [N,1] CPU, stop_time [N] CPU)."""
+        dev, T = self.device, self.max_timesteps
+        n = states["z"].shape[0]
+        clock = start_times.to(dev).to(torch.int64).clone()
+        stopped = torch.zeros(n, dtype=torch.bool, device=dev) if active is None else ~active.to(dev)
+        stopped = stopped | (clock > T)
+        stop_time = torch.full((n,), T, dtype=torch.int64, device=dev)
+        one = torch.ones((), dtype=torch.float32, device=dev)
+        steps = int(T + 1 - int(clock.min())) if n else 0
+        for it in range(max(steps, 0)):
+            # rows that are out of the game are handed a stop action: the engine leaves them untouched (env.py:79-81)
+            act = OrderedDict((k, (torch.where(stopped, one, v) if k == "T" else v)) for k, v in action.items())
+            states, done = self.env.step(states, act)
+            done = torch.as_tensor(done, device=dev).reshape(-1)
+            newly = done & ~stopped
+            stop_time = torch.where(newly, clock, stop_time)
+            stopped = stopped | done | (clock >= T)             # a row whose clock shows T has taken its last step
+            if it % self.sync_every == 0 and bool(stopped.all()):
+                break
+            live = ~stopped
+            self.observe(ctx, clock.clamp(max=T - 1), policy_observation(states["x"]), live)
+            rows = torch.arange(n, device=dev)[live]
+            ctx.er[rows, clock[live]] = pred_rtg[live]
+            new_action, new_rtg = self._predict_rows(ctx, clock)
+            for k in action:
+                action[k] = torch.where(live, new_action[k], action[k])
+            pred_rtg = torch.where(live.reshape(n, 1), new_rtg, pred_rtg)
+            clock = clock + live.to(torch.int64)
         if scorer is not None:
             reward = torch.as_tensor(scorer(states)).reshape(n, 1).float().cpu()
         else:
@@ -127,11 +248,11 @@ class GreedyEvaluator:
             first_state = torch.as_tensor(mat["x0_raw"]) if "x0_raw" in mat else states["x"]
         if first_state.is_complex():
             first_state = first_state.real
-        es, ea, er, et, ek = self.buffers(n, task)
-        es[:, 0] = policy_observation(first_state.to(dev).float().reshape(n, 1, *states["z"].shape[-2:]))
-        er[:, 0, 0] = rtg.reshape(n).to(dev).float()
+        ctx = self.buffers(n, task)
+        self.observe(ctx, 0, policy_observation(first_state.to(dev).float().reshape(n, 1, *states["z"].shape[-2:])))
+        ctx.er[:, 0, 0] = rtg.reshape(n).to(dev).float()
         initial_reward = self.env.compute_reward(states["x"], states["gt"])
-        action, pred_rtg = self._initial(es, ea, er, et, ek)
-        reward, stop_time = self.rollout(states, action, pred_rtg, 1, es, ea, er, et, ek)
+        action, pred_rtg = self._initial(ctx)
+        reward, stop_time = self.rollout(states, action, pred_rtg, 1, ctx)
         return GreedyResult(reward=reward, initial_reward=initial_reward, stop_time=stop_time,
-                            actions=ea.cpu(), x=states["x"])
+                            actions=ctx.ea.cpu(), x=states["x"])

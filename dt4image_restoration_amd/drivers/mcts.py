@@ -1,4 +1,4 @@
-"""Tree search over (sigma_d, mu) on top of the greedy policy.
+"""Tree search over (sigma_d, mu) on top of the greedy policy, batched over images.
 
 Counterpart of /root/reference/evaluation/mcts.py: per round select by p-UCB (`select_p_ucb` :74-88), expand the
 selected node into `n_children` children whose (sigma_d, mu) are sampled around the policy's prediction
@@ -6,41 +6,98 @@ selected node into `n_children` children whose (sigma_d, mu) are sampled around 
 termination (`run_beam_search` :198-207), back up the maximum (`Node.backprop` :34-38), finally report the PSNR of
 the best program (`get_best_program` :165-192).
 
+BASELINE configs[3] scale (`MCTS.run_batch`): B images are searched AT ONCE, one tree per image.  Per round
+  * selection walks each image's tree on the host (a few dozen float comparisons per image);
+  * expansion is ONE policy call on the B selected nodes and ONE `env.step` on B x k rows (the k children of every image,
+    engine of B*k replicas);
+  * simulation is ONE no-reference greedy rollout of B rows with a per-row clock (`GreedyEvaluator.rollout_rows`: the
+    selected nodes of different images sit at different depths; engine of B replicas);
+so a round costs 1 + (rollout length) engine steps however many images are searched.  Node states live in one
+preallocated device pool (x f32, z c64, u c64, T per node; a node is an integer id), filled by index copies.
+
 Deliberate differences (the reference cannot be matched bit for bit here):
   * `env.step` in the reference mutates and returns one shared dict, so a node, its five children and the policy
-    state all alias the same tensors (mcts.py:118-128 vs env.py:95-100).  Here every node owns a snapshot of its
-    (x, z, u, T) and children start from their parent's snapshot - the search the code evidently intends.
-  * ARNIQA (a network fetch) is replaced by an injectable `scorer(states) -> [N]`; sampling uses a seeded generator.
+    state all alias the same tensors (mcts.py:118-128 vs env.py:95-100).  Here every node owns its (x, z, u, T) and
+    children start from their parent's state - the search the code evidently intends.
+  * ARNIQA (a network fetch) is replaced by an injectable `scorer(states) -> [N]`; sampling uses seeded generators, one
+    per image (seed, image index), so an image's search does not depend on which other images share the batch.
   * rewards are backed up to the ancestors (mcts.py:249,255 assign `node.reward = reward` before `backprop(reward)`,
     whose `reward > self.reward` test then never fires).
-  * the children of one expansion are stepped as ONE batch (the engine holds n_children replicas of the image).
 """
 from __future__ import annotations
 
 import math
+import time as _time
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional
 
 import torch
 
 from ..policy import policy_observation
-from .greedy import GreedyEvaluator
+from .greedy import GreedyEvaluator, PolicyContext
+
+
+class NodePool:
+    """Device storage of node states: row `id` of x [cap, H*W] f32, z / u [cap, H*W] c64, T [cap] f32."""
+
+    def __init__(self, capacity: int, h: int, w: int, device):
+        self.h, self.w = h, w
+        self.x = torch.empty((capacity, h * w), dtype=torch.float32, device=device)
+        self.z = torch.empty((capacity, h * w), dtype=torch.complex64, device=device)
+        self.u = torch.empty((capacity, h * w), dtype=torch.complex64, device=device)
+        self.T = torch.empty((capacity,), dtype=torch.float32, device=device)
+        self.used = 0
+
+    def alloc(self, count: int) -> torch.Tensor:
+        if self.used + count > self.x.shape[0]:
+            raise RuntimeError("node pool exhausted")
+        ids = torch.arange(self.used, self.used + count, device=self.x.device)
+        self.used += count
+        return ids
+
+    def store(self, ids: torch.Tensor, states, rows=slice(None)) -> None:
+        n = ids.shape[0]
+        self.x[ids] = states["x"][rows].reshape(n, -1)
+        self.z[ids] = states["z"][rows].reshape(n, -1)
+        self.u[ids] = states["u"][rows].reshape(n, -1)
+        self.T[ids] = states["T"][rows]
+
+    def load(self, ids: torch.Tensor, states, repeat: int = 1) -> None:
+        """states rows <- pool rows `ids`, each repeated `repeat` times (the replicas of one image are adjacent)."""
+        if repeat > 1:
+            ids = ids.repeat_interleave(repeat)
+        shape = states["x"].shape
+        states["x"].copy_(self.x[ids].reshape(shape))
+        states["z"].copy_(self.z[ids].reshape(shape))
+        states["u"].copy_(self.u[ids].reshape(shape))
+        states["T"].copy_(self.T[ids])
 
 
 class Node:
-    def __init__(self, snap, time, prob, parent, edge, action, ob, rtg, index):
-        self.snap = snap              # {'x','z','u','T'} tensors [1,...]: this node's environment state
+    def __init__(self, pool: NodePool, nid: int, time, prob, parent, edge, action, emb, ob, rtg, index):
+        self.pool = pool
+        self.nid = nid                # row of this node's state in the pool
         self.time = time
         self.prob = float(prob)
         self.parent = parent
         self.edge = edge
         self.action = action          # model-order action vector [3] that led here (None for the root)
-        self.ob = ob                  # policy observation of this node's state [16384]
+        self.emb = emb                # cached state-encoder output of this node's observation [E] (or None)
+        self.ob = ob                  # policy observation [16384] (kept only when embeddings are not cached)
         self.rtg = rtg                # return-to-go token written at this node's time step [1]
         self.index = index
         self.children: List["Node"] = []
         self.reward = 0.0
         self.visits = 0
+        self.rollout_reward: Optional[float] = None
+        self.final_x: Optional[torch.Tensor] = None
+
+    @property
+    def snap(self) -> Dict[str, torch.Tensor]:
+        """Views of this node's state in the pool (x [1,1,H,W] f32, z, u c64, T [1])."""
+        p, i = self.pool, self.nid
+        return {"x": p.x[i].view(1, 1, p.h, p.w), "z": p.z[i].view(1, 1, p.h, p.w), "u": p.u[i].view(1, 1, p.h, p.w),
+                "T": p.T[i:i + 1]}
 
     def __repr__(self):
         return f"Node(time = {self.time}, edge = {self.edge})_{self.index}"
@@ -85,77 +142,170 @@ class MCTS:
         self.scorer = scorer
         self.k = n_children
         self.rounds = rounds
-        self.gen = torch.Generator().manual_seed(seed)
+        self.seed = seed
+        self.last_stats: Dict[str, float] = {}
 
     # -- helpers -------------------------------------------------------------------------------------------------
-    def _context(self, node: Node, task: torch.Tensor, n: int):
-        """Rebuild the policy context of `node` from its ancestor chain (mcts.py:40-59 build_eval/build_action),
-        replicated n times."""
-        es, ea, er, et, ek = self.ev.buffers(n, task.expand(n))
+    def _fill_context(self, ctx: PolicyContext, row: int, node: Node) -> None:
+        """Rebuild row `row` of the policy context from `node`'s ancestor chain (mcts.py:40-59 build_eval/build_action)."""
         for nd in node.chain():
-            es[:, nd.time] = nd.ob
-            er[:, nd.time] = nd.rtg
+            if ctx.ee is not None:
+                ctx.ee[row, nd.time] = nd.emb
+            if nd.ob is not None:
+                ctx.es[row, nd.time] = nd.ob
+            ctx.er[row, nd.time] = nd.rtg
             if nd.action is not None and nd.time >= 1:
-                ea[:, nd.time - 1] = nd.action
-        return es, ea, er, et, ek
+                ctx.ea[row, nd.time - 1] = nd.action
 
-    def _load(self, states, snap, rows):
-        for key in ("x", "z", "u", "T"):
-            states[key][rows] = snap[key]
+    def _context(self, nodes: List[Node], task: torch.Tensor) -> PolicyContext:
+        ctx = self.ev.buffers(len(nodes), task)
+        for b, nd in enumerate(nodes):
+            self._fill_context(ctx, b, nd)
+        return ctx
 
-    def _plan(self, node: Node, ctx):
-        es, ea, er, et, ek = ctx
-        if node.time == 0:
-            return self.ev._initial(es, ea, er, et, ek)
-        return self.ev._predict(es, ea, er, et, ek, node.time)
+    def _plan(self, nodes: List[Node], ctx: PolicyContext):
+        """Policy proposal at each row's node: `_initial` for roots, `_predict` at the node's own time otherwise."""
+        times = [nd.time for nd in nodes]
+        if all(t == 0 for t in times):
+            return self.ev._initial(ctx)
+        if len(set(times)) == 1:
+            return self.ev._predict(ctx, times[0])
+        dev = self.ev.device
+        tv = torch.tensor(times, dtype=torch.int64, device=dev)
+        roots = tv == 0
+        if not bool(roots.any()):
+            return self.ev._predict_rows(ctx, tv)
+        # mixed: roots use the first-step call (eval.py:80-98), the others their own time.  Both calls write the action they
+        # picked into the context for EVERY row (ea[:, 0] / ea[row, t]); keep each row's write from its own call only.
+        ea0, ea1 = ctx.ea[:, 0].clone(), ctx.ea[:, 1].clone()
+        a0, r0 = self.ev._initial(ctx)
+        ctx.ea[~roots, 0] = ea0[~roots]
+        action, prtg = self.ev._predict_rows(ctx, tv.clamp(min=1))
+        ctx.ea[roots, 1] = ea1[roots]
+        for k in action:
+            action[k] = torch.where(roots, a0[k], action[k])
+        return action, torch.where(roots.reshape(-1, 1), r0, prtg)
 
     # -- search --------------------------------------------------------------------------------------------------
-    def run(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor):
-        """One image (batch 1 in `mat`).  Returns (best PSNR [1,1], root)."""
-        k, dev = self.k, self.ev.device
-        rep = {key: (torch.as_tensor(v).expand(k, *torch.as_tensor(v).shape[1:]).contiguous() if key != "mask" else v)
-               for key, v in mat.items()}
-        states = self.env.reset(rep, dev)                       # k replicas: children are stepped as one batch
-        root_snap = {key: states[key][:1].clone() for key in ("x", "z", "u", "T")}
-        root = Node(root_snap, 0, 1.0, None, 0, None, policy_observation(states["x"][:1])[0],
-                    rtg.reshape(1).to(dev).float(), 0)
-        cache: Dict[str, float] = {}
-        finals: Dict[str, torch.Tensor] = {}
+    def run_batch(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
+                  first_state: Optional[torch.Tensor] = None):
+        """B images at once (one tree each).  Returns (best PSNR [B,1] CPU, list of B roots)."""
+        k, dev, ev = self.k, self.ev.device, self.ev
+        mat = {key: torch.as_tensor(v) for key, v in mat.items()}
+        B = mat["gt"].shape[0]
+        t_start = _time.perf_counter()
+        # engine of B rows for the rollouts, engine of B*k rows for the expansions (the k children of an image are adjacent)
+        rep = {key: (v.repeat_interleave(k, dim=0) if key != "mask" and v.dim() > 2 else v) for key, v in mat.items()}
+        st_roll = self.env.reset(mat, dev)
+        st_exp = self.env.reset(rep, dev)
+        h, w = st_roll["z"].shape[-2:]
+        pool = NodePool(B * (1 + k * self.rounds), h, w, dev)
+        cache_emb = ev.cache_state_embeddings
+
+        def observation(x):                                      # -> (emb [n,E] or None, ob [n,16384] or None)
+            ob = policy_observation(x)
+            return (ev.model.encode_states(ob), None) if cache_emb else (None, ob)
+
+        if first_state is None:
+            first_state = mat["x0_raw"] if "x0_raw" in mat else st_roll["x"]
+        if first_state.is_complex():
+            first_state = first_state.real
+        with torch.no_grad():
+            emb0, ob0 = observation(first_state.to(dev).float().reshape(B, 1, h, w))
+        root_ids = pool.alloc(B)
+        pool.store(root_ids, st_roll)
+        rtg0 = rtg.reshape(B, 1).to(dev).float()
+        roots = [Node(pool, int(root_ids[b]), 0, 1.0, None, 0, None, None if emb0 is None else emb0[b],
+                      None if ob0 is None else ob0[b], rtg0[b], 0) for b in range(B)]
+        gens = [torch.Generator().manual_seed(self.seed * 1000003 + b) for b in range(B)]
+        order = list(ev.model.action_range.keys())
+        n_rollouts = 0
         for rnd in range(self.rounds):
-            node = root
-            node.visits += 1
-            while node.children:                                # selection
-                node = select_p_ucb(node, node.children)
+            # ---- selection (host) ----
+            sel: List[Node] = []
+            for b in range(B):
+                node = roots[b]
                 node.visits += 1
-            if node.time >= self.ev.max_timesteps - 1:
-                node.backprop(node.reward)
+                while node.children:
+                    node = select_p_ucb(node, node.children)
+                    node.visits += 1
+                sel.append(node)
+            expand = [nd.time < ev.max_timesteps - 1 for nd in sel]
+            for nd, ex in zip(sel, expand):
+                if not ex:
+                    nd.backprop(nd.reward)
+            if not any(expand):
                 continue
-            # expansion: policy proposal at the node, k perturbed children stepped in one batch
-            ctx = self._context(node, task, k)
-            action, pred_rtg = self._plan(node, ctx)
-            sig, probs = sample_around(float(action["sigma_d"][0]), 0.2, k, self.gen)
-            mu, _ = sample_around(float(action["mu"][0]), 0.001, k, self.gen)
-            child_action = OrderedDict(action)
-            child_action["sigma_d"] = sig.to(dev)
-            child_action["mu"] = mu.to(dev)
-            self._load(states, node.snap, slice(None))
-            states, _ = self.env.step(states, child_action)
-            obs = policy_observation(states["x"])
-            order = list(self.ev.model.action_range.keys())
-            for i in range(k):
-                vec = torch.stack([child_action[key][i] for key in order])
-                snap = {key: states[key][i:i + 1].clone() for key in ("x", "z", "u", "T")}
-                node.children.append(Node(snap, node.time + 1, probs[i], node, i, vec, obs[i], pred_rtg[0], rnd))
-            # simulation: no-reference greedy rollout from the node itself (mcts.py:242-252)
-            key = repr(node)
-            if key not in cache:
-                self._load(states, node.snap, slice(None))
-                ctx = self._context(node, task, k)
-                act, prtg = self._plan(node, ctx)
-                reward, _ = self.ev.rollout(states, act, prtg, node.time + 1, *ctx, scorer=self.scorer)
-                cache[key] = float(reward[0])
-                finals[key] = states["x"][:1].clone()
-            node.backprop(cache[key])       # (the reference assigns node.reward first, which turns its own backprop into a no-op)
-        best = max(cache, key=cache.get)
-        psnr = self.env.compute_reward(finals[best].expand(k, -1, -1, -1).contiguous(), states["gt"])[:1]
-        return psnr, root
+            # ---- expansion: one policy call on the B selected nodes, one env.step on their B*k children ----
+            ctx = self._context(sel, task)
+            action, pred_rtg = self._plan(sel, ctx)
+            a_cpu = {key: action[key].detach().float().cpu() for key in ("sigma_d", "mu")}      # one sync per round
+            sig = torch.empty(B, k); mu = torch.empty(B, k); probs = torch.empty(B, k)
+            for b in range(B):
+                sig[b], probs[b] = sample_around(float(a_cpu["sigma_d"][b]), 0.2, k, gens[b])
+                mu[b], _ = sample_around(float(a_cpu["mu"][b]), 0.001, k, gens[b])
+            child_action = OrderedDict((key, v.repeat_interleave(k)) for key, v in action.items())
+            child_action["sigma_d"] = sig.reshape(-1).to(dev)
+            child_action["mu"] = mu.reshape(-1).to(dev)
+            if not all(expand):                                   # images whose selected node is terminal sit this round out
+                ex_rows = torch.tensor(expand, device=dev).repeat_interleave(k)
+                child_action["T"] = torch.where(ex_rows, child_action["T"], torch.ones_like(child_action["T"]))
+            sel_ids = torch.tensor([nd.nid for nd in sel], device=dev)
+            pool.load(sel_ids, st_exp, repeat=k)
+            st_exp, _ = self.env.step(st_exp, child_action)
+            with torch.no_grad():
+                emb_c, ob_c = observation(st_exp["x"])
+            child_ids = pool.alloc(B * k)
+            pool.store(child_ids, st_exp)
+            cid = child_ids.tolist()
+            vecs = torch.stack([child_action[key] for key in order], dim=1)                      # [B*k, 3] model order
+            for b in range(B):
+                if not expand[b]:
+                    continue
+                nd = sel[b]
+                for i in range(k):
+                    r = b * k + i
+                    nd.children.append(Node(pool, cid[r], nd.time + 1, probs[b, i], nd, i, vecs[r],
+                                            None if emb_c is None else emb_c[r], None if ob_c is None else ob_c[r],
+                                            pred_rtg[b], rnd))
+            # ---- simulation: no-reference greedy rollout from the selected node itself (mcts.py:242-252), B rows, per-row clock
+            need = [expand[b] and sel[b].rollout_reward is None for b in range(B)]
+            if any(need):
+                pool.load(sel_ids, st_roll)
+                ctx = self._context(sel, task)
+                act, prtg = self._plan(sel, ctx)
+                starts = torch.tensor([nd.time + 1 for nd in sel], dtype=torch.int64)
+                reward, _ = ev.rollout_rows(st_roll, act, prtg, starts, ctx, scorer=self.scorer,
+                                            active=torch.tensor(need))
+                finals = st_roll["x"].clone()
+                for b in range(B):
+                    if need[b]:
+                        sel[b].rollout_reward = float(reward[b])
+                        sel[b].final_x = finals[b:b + 1]
+                        n_rollouts += 1
+            for b in range(B):
+                if expand[b]:
+                    # (the reference assigns node.reward first, which turns its own backprop into a no-op)
+                    sel[b].backprop(sel[b].rollout_reward)
+        # ---- best program per image: the rollout with the highest score; its PSNR (mcts.py:165-192) ----
+        best_x = []
+        for b in range(B):
+            best, stack = None, [roots[b]]
+            while stack:
+                nd = stack.pop()
+                stack += nd.children
+                if nd.rollout_reward is not None and (best is None or nd.rollout_reward > best.rollout_reward):
+                    best = nd
+            best_x.append(best.final_x if best is not None else roots[b].snap["x"])
+        psnr = self.env.compute_reward(torch.cat(best_x, dim=0).contiguous(), st_roll["gt"])
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        dt = _time.perf_counter() - t_start
+        self.last_stats = {"images": B, "rounds": self.rounds, "rollouts": n_rollouts, "seconds": dt,
+                           "rollouts_per_s": n_rollouts / dt if dt > 0 else 0.0, "nodes": pool.used}
+        return psnr, roots
+
+    def run(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
+            first_state: Optional[torch.Tensor] = None):
+        """One image (batch 1 in `mat`), the reference's call shape (mcts.py:212).  Returns (best PSNR [1,1], root)."""
+        psnr, roots = self.run_batch(mat, rtg, task, first_state)
+        return psnr[:1], roots[0]

@@ -125,13 +125,22 @@ class DecisionTransformer(nn.Module):
             action_dict[key] = part * rng["scale"] + rng["shift"]
         return torch.cat(list(action_dict.values()), dim=-1), action_dict
 
+    def encode_states(self, states: torch.Tensor) -> torch.Tensor:
+        """[..., 16384] observations -> [..., E] state-encoder outputs (before the task embedding is added).  The encoder
+        is a pure per-image function, so a driver may run it ONCE per observation and hand the cached result to `forward`
+        (`state_emb=`) instead of re-encoding the whole context window in both forwards of every step as the reference does
+        (eval.py:150-186: 2 x 6 images per step and slice)."""
+        lead = states.shape[:-1]
+        return self.state_encoder(states.reshape(-1, 1, 128, 128)).reshape(*lead, -1)
+
     def forward(self, rtg, states, timesteps, task, actions: Optional[torch.Tensor] = None,
-                eval_rtg: bool = False, eval_actions: bool = False):
+                eval_rtg: bool = False, eval_actions: bool = False, state_emb: Optional[torch.Tensor] = None):
         """rtg [B,T,1]; states [B,T,16384]; timesteps [B,T,1]; task [B,T]; actions [B,T,3] or None.
-        Token order per step: (rtg, state, action) or (rtg, state) when actions is None (:212-263)."""
-        b, t, _ = states.shape
+        Token order per step: (rtg, state, action) or (rtg, state) when actions is None (:212-263).
+        state_emb [B,T,E]: `encode_states(states)` computed earlier (then `states` is only read for its shape)."""
+        b, t = states.shape[0], states.shape[1]
         rtg_e = self.embed_return(rtg)
-        st_e = self.state_encoder(states.reshape(-1, 1, 128, 128)).reshape(b, t, -1)
+        st_e = self.encode_states(states) if state_emb is None else state_emb
         time_e = self.time_embed(timesteps.to(torch.int64).reshape(b, -1))
         st_e = st_e + self.task_embed(task)
         per = 3 if actions is not None else 2

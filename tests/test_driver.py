@@ -286,3 +286,98 @@ def test_cli_eval_on_a_directory_of_mat_files(tmp_path):
     assert abs(out[0]["psnr"] - float(r.reward.mean())) < 1e-4
     assert abs(out[0]["psnr_increment"] - float((r.reward - r.initial_reward).mean())) < 1e-4
     assert 20 < out[0]["psnr"] < 45
+
+
+def test_per_row_clock_rollout_equals_scalar_rollout():
+    """`rollout_rows` (per-row clock, what the batched tree search uses) with equal start times is the scalar `rollout`
+    bit for bit - on the oracle-backed env, 2 slices with different stop behaviour; and the cached state embeddings give
+    the same actions as re-encoding the window in both forwards like the reference (eval.py:150-186)."""
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=0.0, head_gain=12.0))
+    problem = synthetic.make_problem(2, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+    rtg = torch.tensor([D.normalised_rtg(10.0), D.normalised_rtg(6.0)])
+    task = torch.tensor([5, 4])
+
+    def go(rows: bool, cache: bool):
+        env = OracleEnv()
+        ev = GreedyEvaluator(m, env, max_timesteps=9, block_size=18, device_type="cpu", cache_state_embeddings=cache)
+        st = env.reset(mat, "cpu")
+        ctx = ev.buffers(2, task)
+        ev.observe(ctx, 0, policy_observation(torch.from_numpy(problem["x0_raw"]).float()))
+        ctx.er[:, 0, 0] = rtg
+        action, prtg = ev._initial(ctx)
+        if rows:
+            reward, stop = ev.rollout_rows(st, action, prtg, torch.tensor([1, 1]), ctx)
+        else:
+            reward, stop = ev.rollout(st, action, prtg, 1, ctx)
+        return reward, stop, ctx.ea.clone()
+
+    r0, s0, a0 = go(False, True)
+    r1, s1, a1 = go(True, True)
+    assert torch.equal(s0, s1) and torch.equal(a0, a1) and torch.equal(r0, r1)
+    r2, s2, a2 = go(False, False)
+    assert torch.equal(s0, s2)
+    # FLOAT TOLERANCE: the encoder runs on 2 images at a time instead of 12 (another blocking of the same f32 convolution)
+    np.testing.assert_allclose(a0.numpy(), a2.numpy(), atol=1e-6)
+    np.testing.assert_allclose(r0.numpy(), r2.numpy(), atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_mcts_configs3_scale_batched_over_images():
+    """BASELINE configs[3]: 256x256, 64 rollouts per image, the reference's 5 children per expansion - searched for 4 images
+    AT ONCE (one tree per image; per round one policy call, one env.step on 4 x 5 children and one per-row-clock rollout of 4
+    rows), stub scorer (ARNIQA is a network fetch), fixed seed.  Checks: reproducible; every image got 64 rollouts and a
+    tree of 1 + 5 x 64 nodes; rewards back up as maxima; the reported PSNR is that of the best-scored rollout's image; and an
+    image's search does not depend on its batch mates (per-image sampling streams): searched alone it finds the same tree
+    size and (to rounding: another tile plan at batch 1) the same PSNR."""
+    import torch.nn.functional as F
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.drivers.mcts import MCTS
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=12.0))
+
+    def scorer(states):
+        x = states["x"]
+        return 1.0 / (1e-3 + ((x - F.avg_pool2d(x, 3, 1, 1)) ** 2).mean(dim=(1, 2, 3)))
+
+    B, R = 4, 64
+    problem = synthetic.make_problem(B, 256, 256, accel=4.0, seed=9)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+    rtg = torch.full((B,), D.normalised_rtg(10.0))
+    task = torch.full((B,), 4)
+
+    def search(sel=None):
+        ev = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), max_timesteps=30, device_type="cuda", sync_every=4)
+        tree = MCTS(ev, scorer, n_children=5, rounds=R, seed=11)
+        mm = mat if sel is None else {k: (v[sel] if k != "mask" else v) for k, v in mat.items()}
+        n = B if sel is None else len(sel)
+        psnr, roots = tree.run_batch(mm, rtg[:n], task[:n])
+        return psnr, roots, tree.last_stats
+
+    p1, roots, stats = search()
+    p2, _, _ = search()
+    assert torch.equal(p1, p2)                                                    # seeded -> reproducible
+    assert stats["rollouts"] == B * R and stats["nodes"] == B * (1 + 5 * R)
+    print(f"\\nMCTS configs[3] geometry: {B} images x {R} rollouts at 256x256 in {stats['seconds']:.2f} s = "
+          f"{stats['rollouts_per_s']:.1f} rollouts/s")
+    for b in range(B):
+        n_nodes, n_roll, best, stack = 0, 0, None, [roots[b]]
+        while stack:
+            nd = stack.pop()
+            n_nodes += 1
+            stack += nd.children
+            if nd.rollout_reward is not None:
+                n_roll += 1
+                best = nd if best is None or nd.rollout_reward > best.rollout_reward else best
+            for c in nd.children:
+                assert c.time == nd.time + 1 and c.reward <= nd.reward + 1e-12       # max-backup
+        assert n_nodes == 1 + 5 * R and n_roll == R and roots[b].visits == R
+        assert abs(roots[b].reward - best.rollout_reward) < 1e-9                     # the root holds the best rollout score
+        assert 15.0 < float(p1[b]) < 45.0
+    # per-image streams: image 0 alone (batch 1: another tile plan, rounding-level differences in the images)
+    q, r1, s1 = search([0])
+    assert s1["nodes"] == 1 + 5 * R
+    assert abs(float(q[0]) - float(p1[0])) < 0.05

@@ -50,3 +50,68 @@ def test_two_rank_sharded_episode_equals_single_process(tmp_path):
 def test_gather_is_identity_without_a_process_group():
     t = torch.arange(5.0)
     assert torch.equal(sharding.gather_per_slice(t, 5), t)
+
+
+# ---- the product entry point for configs[2] (drivers/sharded.run_sharded_greedy) under 2 gloo ranks ----------------------
+GT, GH, GSTEPS = 3, 128, 4
+
+
+def _greedy_parts():
+    from dt4image_restoration_amd import data as D
+    from dt4image_restoration_amd.drivers.greedy import GreedyEvaluator
+    from dt4image_restoration_amd.policy import DecisionTransformer, DecisionTransformerConfig
+
+    class OracleEnv:                                        # PnPEnv-shaped wrapper over the CPU oracle (tests only)
+        def __init__(self):
+            self.sd = O.torch_weights(weights.generate_unet_weights(0, "unit_gain"))
+
+        def reset(self, mat, device):
+            return O.reset({k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in mat.items()})
+
+        def step(self, st, action):
+            with torch.no_grad():
+                return O.admm_step(self.sd, st, action["mu"], action["sigma_d"], action["T"])
+
+        def compute_reward(self, x, gt):
+            return O.psnr(x, gt)
+
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=8.0))
+    ev = GreedyEvaluator(m, OracleEnv(), max_timesteps=GSTEPS, block_size=18, device_type="cpu", sync_every=2)
+
+    def load_shard(a, b):
+        p = synthetic.make_problem(b - a, GH, GH, accel=4.0, seed=77, first_slice=a)
+        mat = {k: torch.from_numpy(np.asarray(v)) for k, v in p.items()}
+        return mat, torch.full((b - a,), D.normalised_rtg(10.0)), torch.full((b - a,), 4)
+    return ev, load_shard
+
+
+def _greedy_worker(rank, world, port, out_dir):
+    from dt4image_restoration_amd.drivers.sharded import run_sharded_greedy
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ev, load_shard = _greedy_parts()
+    r = run_sharded_greedy(ev, GT, load_shard)
+    assert r.local_range == sharding.shard_range(GT, rank, world)
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), reward=r.reward.numpy(), stop=r.stop_time.numpy(), init=r.initial_reward.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_greedy_rollout_equals_single_process(tmp_path):
+    """configs[2]'s code path: DT-driven rollout per rank on its shard + the PSNR / stop-iteration gather, 2 gloo ranks with
+    ragged shards (2 + 1 slices), equals the unsharded run of the same entry point."""
+    from dt4image_restoration_amd.drivers.sharded import run_sharded_greedy
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_greedy_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ev, load_shard = _greedy_parts()
+    want = run_sharded_greedy(ev, GT, load_shard)          # no process group: world size 1
+    assert want.reward.shape == (GT, 1) and want.stop_time.shape == (GT,)
+    for r in range(2):
+        got = np.load(tmp_path / f"g{r}.npz")
+        np.testing.assert_array_equal(got["stop"], want.stop_time.numpy())
+        # FLOAT TOLERANCE: a slice alone or in a batch of 2 takes another oneDNN blocking of the same f32 convolutions
+        np.testing.assert_allclose(got["reward"], want.reward.numpy(), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(got["init"], want.initial_reward.numpy(), rtol=0, atol=1e-4)

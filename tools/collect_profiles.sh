@@ -7,14 +7,14 @@ TAG=${1:-r02}; N=${2:-1}
 R=$(pwd); G=$R/gpurun_out; mkdir -p "$G"
 python3 bench.py > "$G/bench_$TAG.json" 2> "$G/bench_$TAG.err"
 echo "bench done: $(cut -c1-120 "$G/bench_$TAG.json")"
-python3 bench.py --no-cpu-baseline --dump-layers "$G/layers_$TAG.json" > "$G/bench_layers_$TAG.json" 2>> "$G/bench_$TAG.err"   # an event pair per launch
+python3 bench.py --no-cpu-baseline --no-greedy --dump-layers "$G/layers_$TAG.json" > "$G/bench_layers_$TAG.json" 2>> "$G/bench_$TAG.err"   # an event pair per launch
 echo "layer table done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$G/prof_$TAG" -o runc -- python3 "$R/bench.py" --steps 10 --warmup 2 --reps 3 --no-cpu-baseline > "$G/bench_prof_$TAG.json" 2> "$G/prof_$TAG.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$G/prof_$TAG" -o runc -- python3 "$R/bench.py" --steps 10 --warmup 2 --reps 3 --no-cpu-baseline --no-greedy > "$G/bench_prof_$TAG.json" 2> "$G/prof_$TAG.err"
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$G/pmcF$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline > /dev/null 2> "$G/pmcF$N.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$G/pmcF$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcF$N.err"
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$G/pmcW$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline > /dev/null 2> "$G/pmcW$N.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$G/pmcW$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcW$N.err"
 echo "write done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$G/pmcS$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline > /dev/null 2> "$G/pmcS$N.err"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$G/pmcS$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcS$N.err"
 echo "sq done"
