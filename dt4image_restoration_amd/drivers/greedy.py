@@ -86,26 +86,28 @@ class GreedyEvaluator:
         return PolicyContext(es, ea, er, et, ek, ee)
 
     @torch.no_grad()
-    def observe(self, ctx: PolicyContext, time, ob: torch.Tensor, rows: Optional[torch.Tensor] = None) -> None:
-        """Write observation `ob` [n,16384] at step `time` (int, or a per-row int64 tensor) for `rows` (bool mask or None)."""
+    def observe(self, ctx: PolicyContext, time, ob: torch.Tensor, rows: Optional[torch.Tensor] = None,
+                rtg: Optional[torch.Tensor] = None) -> None:
+        """Write observation `ob` [n,16384] (and, if given, the return-to-go token `rtg` [n,1]) at step `time` (int, or a
+        per-row int64 tensor) for `rows` (bool mask or None = all).  Masked writes are selects, not boolean-mask indexing:
+        no `nonzero`, so no host synchronisation in the rollout loop."""
         emb = self.model.encode_states(ob) if ctx.ee is not None else None
+        n = ob.shape[0]
         if isinstance(time, int):
-            if rows is None:
-                ctx.es[:, time] = ob
-                if emb is not None:
-                    ctx.ee[:, time] = emb
-            else:
-                ctx.es[rows, time] = ob[rows]
-                if emb is not None:
-                    ctx.ee[rows, time] = emb[rows]
+            sel = None if rows is None else rows.reshape(n, 1)
+            ctx.es[:, time] = ob if sel is None else torch.where(sel, ob, ctx.es[:, time])
+            if emb is not None:
+                ctx.ee[:, time] = emb if sel is None else torch.where(sel, emb, ctx.ee[:, time])
+            if rtg is not None:
+                ctx.er[:, time] = rtg if sel is None else torch.where(sel, rtg, ctx.er[:, time])
             return
-        idx = torch.arange(ob.shape[0], device=ob.device)
-        if rows is not None:
-            idx, time, ob = idx[rows], time[rows], ob[rows]
-            emb = None if emb is None else emb[rows]
-        ctx.es[idx, time] = ob
+        idx = torch.arange(n, device=ob.device)
+        sel = None if rows is None else rows.reshape(n, 1)
+        ctx.es[idx, time] = ob if sel is None else torch.where(sel, ob, ctx.es[idx, time])
         if emb is not None:
-            ctx.ee[idx, time] = emb
+            ctx.ee[idx, time] = emb if sel is None else torch.where(sel, emb, ctx.ee[idx, time])
+        if rtg is not None:
+            ctx.er[idx, time] = rtg if sel is None else torch.where(sel, rtg, ctx.er[idx, time])
 
     # ---- policy calls --------------------------------------------------------------------------------------
     def _pick(self, action_dict, pred_actions, pos: int):
@@ -179,15 +181,14 @@ class GreedyEvaluator:
         for time in range(start_time, T + 1):
             states, done = self.env.step(states, action)
             done = torch.as_tensor(done, device=dev).reshape(-1)
-            stop_time[done & ~stopped] = time
-            stopped |= done
+            stop_time = torch.where(done & ~stopped, torch.full_like(stop_time, time), stop_time)
+            stopped = stopped | done
             if time == T:
                 break
             if (time - start_time) % self.sync_every == 0 and bool(stopped.all()):      # the loop's only host sync
                 break
             live = ~stopped
-            self.observe(ctx, time, policy_observation(states["x"]), live)
-            ctx.er[live, time] = pred_rtg[live]
+            self.observe(ctx, time, policy_observation(states["x"]), live, rtg=pred_rtg)
             new_action, new_rtg = self._predict(ctx, time)
             for k in action:                                   # stopped slices keep the action that stopped them
                 action[k] = torch.where(live, new_action[k], action[k])
@@ -222,9 +223,7 @@ class GreedyEvaluator:
             if it % self.sync_every == 0 and bool(stopped.all()):
                 break
             live = ~stopped
-            self.observe(ctx, clock.clamp(max=T - 1), policy_observation(states["x"]), live)
-            rows = torch.arange(n, device=dev)[live]
-            ctx.er[rows, clock[live]] = pred_rtg[live]
+            self.observe(ctx, clock.clamp(max=T - 1), policy_observation(states["x"]), live, rtg=pred_rtg)
             new_action, new_rtg = self._predict_rows(ctx, clock)
             for k in action:
                 action[k] = torch.where(live, new_action[k], action[k])
