@@ -401,6 +401,193 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
     }
 }
 
+// ---- 128 x 128: the whole data-fidelity stage of a slice in ONE workgroup ------------------------------------------------
+// A 128 x 128 complex64 slice is 128 KiB, less than the 160 KiB of LDS a workgroup may own: v = x + u is read once, both
+// forward transforms, the masked solve, both inverse transforms and the dual update happen in LDS, z and u are written once.
+// HBM traffic = the algorithmic 37 B/px (x 4 + u 8 + y0 8 + mask 1 read, z 8 + u 8 written) instead of the 81 B/px of the
+// three-launch path, and one launch instead of three on the reference's own problem size (env.py:44,64: 128 x 128).
+// In-place Stockham passes with a register batch as the second buffer (every butterfly of a pass is read, barrier, written);
+// 1024 threads: 4 radix-4 butterflies (8 radix-2) per thread and pass.  Lines are rows (element stride 1, line stride 129) or
+// columns (element stride 129, line stride 1) of the same padded image: both access patterns are bank-conflict-free.
+template <bool INV, int L, int LINES, int LS, int ES, int NS, int NT>
+__device__ __forceinline__ void fft_pass4_strided(float2* buf, const float2* __restrict__ tw) {
+    constexpr int per4 = L / 4, IT = LINES * per4 / NT, tstep = L / (4 * NS);
+    static_assert((LINES * per4) % NT == 0, "whole batches of butterflies");
+    const int tid = threadIdx.x;
+    float2 v[IT][4], w[IT][3];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int line = idx / per4, j = idx % per4;
+        const float2* sp = buf + line * LS + j * ES;
+        v[it][0] = sp[0]; v[it][1] = sp[per4 * ES]; v[it][2] = sp[2 * per4 * ES]; v[it][3] = sp[3 * per4 * ES];
+        if (NS > 1) {
+            const int k = j & (NS - 1);
+            w[it][0] = tw[k * tstep]; w[it][1] = tw[2 * k * tstep]; w[it][2] = tw[3 * k * tstep];
+        }
+    }
+    __syncthreads();                                       // in place: every read of the pass before any write
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int line = idx / per4, j = idx % per4;
+        const int k = j & (NS - 1);
+        float2 v0 = v[it][0], v1 = v[it][1], v2 = v[it][2], v3 = v[it][3];
+        if (NS > 1) {
+            float2 w1 = w[it][0], w2 = w[it][1], w3 = w[it][2];
+            if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+        }
+        const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3);
+        const float2 d = csub(v1, v3);
+        const float2 t3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+/- i) * d
+        float2* dp = buf + line * LS + (((j - k) << 2) + k) * ES;
+        dp[0] = cadd(t0, t2);
+        dp[NS * ES] = cadd(t1, t3);
+        dp[2 * NS * ES] = csub(t0, t2);
+        dp[3 * NS * ES] = csub(t1, t3);
+    }
+    __syncthreads();
+}
+
+template <bool INV, int L, int LINES, int LS, int ES, int NS, int NT>
+__device__ __forceinline__ void fft_pass2_strided(float2* buf, const float2* __restrict__ tw) {
+    constexpr int per2 = L / 2, IT = LINES * per2 / NT;
+    static_assert((LINES * per2) % NT == 0 && NS * 2 == L, "radix-2 tail");
+    const int tid = threadIdx.x;
+    float2 v[IT][2], w[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int line = idx / per2, j = idx % per2;
+        const float2* sp = buf + line * LS + j * ES;
+        v[it][0] = sp[0]; v[it][1] = sp[per2 * ES];
+        w[it] = tw[j & (NS - 1)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int line = idx / per2, j = idx % per2;
+        const int k = j & (NS - 1);
+        float2 ww = w[it];
+        if (INV) ww.y = -ww.y;
+        const float2 v1 = cmul(v[it][1], ww);
+        float2* dp = buf + line * LS + (((j - k) << 1) + k) * ES;
+        dp[0] = cadd(v[it][0], v1);
+        dp[NS * ES] = csub(v[it][0], v1);
+    }
+    __syncthreads();
+}
+
+// 128-point transforms of all 128 lines: 4 * 4 * 4 * 2
+template <bool INV, int LS, int ES, int NT>
+__device__ __forceinline__ void fft128_all_lines(float2* buf, const float2* tw) {
+    fft_pass4_strided<INV, 128, 128, LS, ES, 1, NT>(buf, tw);
+    fft_pass4_strided<INV, 128, 128, LS, ES, 4, NT>(buf, tw);
+    fft_pass4_strided<INV, 128, 128, LS, ES, 16, NT>(buf, tw);
+    fft_pass2_strided<INV, 128, 128, LS, ES, 64, NT>(buf, tw);
+}
+
+__global__ __launch_bounds__(1024) void admm_slice128_kernel(const float* __restrict__ x, float2* __restrict__ z,
+                                                             float2* u, const float2* __restrict__ twg,
+                                                             const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
+                                                             int mask_n, const float* __restrict__ mu,
+                                                             const float* __restrict__ tact) {
+    constexpr int L = 128, LP = L + 1, NT = 1024, PER = L * L / NT, HB = PER / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2* const buf = smem;                              // [128][129]
+    float2* const tw = smem + L * LP;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tact != nullptr && tact[n] > 0.5f) return;
+    const size_t base = (size_t)n * L * L;
+    if (tid < L) tw[tid] = twg[tid];
+    // global accesses in batches of 8 independent requests per thread (1024 threads leave 128 registers each: 16 requests
+    // of 12 B with their addresses do not fit)
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        float2 uu[HB];
+        float xv[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int e = tid + (h * HB + k) * NT;
+            uu[k] = u[base + e];
+            xv[k] = x[base + e];
+        }
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int e = tid + (h * HB + k) * NT;
+            buf[(e >> 7) * LP + (e & 127)] = make_float2(xv[k] + uu[k].x, uu[k].y);   // v = x + u (env.py:87)
+        }
+    }
+    __syncthreads();
+    fft128_all_lines<false, LP, 1, NT>(buf, tw);           // rows
+    fft128_all_lines<false, 1, LP, NT>(buf, tw);           // columns
+    {
+        // masked closed-form solve on the sampled bins (env.py:88-90), constants pre-shifted by pnp_reset; the two
+        // orthonormal scalings 1/sqrt(128) * 1/sqrt(128) = 2^-7 are exact
+        const float m = mu[n], inv1m = 1.f + m, sc = 1.f / 128.f;
+        const float2* y0n = y0s + base;
+        const uint8_t* mk = masks + (mask_n > 1 ? base : 0);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            float2 yy[HB];
+            uint8_t mm[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int e = tid + (h * HB + k) * NT;
+                mm[k] = mk[e];
+                yy[k] = y0n[e];
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int e = tid + (h * HB + k) * NT;
+                float2* p = &buf[(e >> 7) * LP + (e & 127)];
+                float2 v = *p;
+                v.x *= sc; v.y *= sc;
+                if (mm[k]) {
+                    v.x = (m * v.x + yy[k].x) / inv1m;
+                    v.y = (m * v.y + yy[k].y) / inv1m;
+                }
+                *p = v;
+            }
+        }
+    }
+    __syncthreads();
+    fft128_all_lines<true, 1, LP, NT>(buf, tw);            // columns back
+    fft128_all_lines<true, LP, 1, NT>(buf, tw);            // rows back
+    // x and u once more for the dual update (not carried in registers across eight transform passes); the second read is
+    // served by this XCD's L2 - the lines were fetched a few microseconds ago
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        float2 uu[HB];
+        float xv[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int e = tid + (h * HB + k) * NT;
+            uu[k] = u[base + e];
+            xv[k] = x[base + e];
+        }
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int e = tid + (h * HB + k) * NT;
+            float2 v = buf[(e >> 7) * LP + (e & 127)];
+            v.x *= 1.f / 128.f; v.y *= 1.f / 128.f;
+            z[base + e] = v;                                                          // z (env.py:91)
+            u[base + e] = make_float2(uu[k].x + xv[k] - v.x, uu[k].y - v.y);          // u + x - z (env.py:93)
+        }
+    }
+}
+
+hipError_t launch_admm_slice128(const float* x, float2* z, float2* u, const float2* tw, const float2* y0s,
+                                const uint8_t* masks, int mask_n, const float* mu, const float* tact, int N, hipStream_t s) {
+    constexpr size_t lds = (size_t)(128 * 129 + 128) * sizeof(float2);
+    static DeviceOnce once;
+    if (hipError_t e = pnp::raise_lds_cap((const void*)admm_slice128_kernel, (int)lds, once); e != hipSuccess) return e;
+    hipLaunchKernelGGL(admm_slice128_kernel, dim3(N), dim3(1024), lds, s, x, z, u, tw, y0s, masks, mask_n, mu, tact);
+    return hipGetLastError();
+}
+
 // The column pass needs up to ~74 KiB of dynamic LDS (H = 1024); raise the per-kernel cap once.
 static hipError_t raise_lds_cap() {
     static DeviceOnce once[5];

@@ -18,6 +18,7 @@ struct Tuning {
     bool no_wino = false;         // PNP_NO_WINOGRAD
     int f4_min_cin = 64;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
+    bool no_slice128 = false;     // PNP_NO_SLICE128: 128 x 128 through the three-launch data-fidelity path (tests compare)
 };
 Tuning tuning_from_env();
 
@@ -124,6 +125,11 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
                                 int mask_n, const float* mu, const float* tact, int N, int H, int W, hipStream_t s);
 hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
                                     const float* tact, int N, int H, int W, hipStream_t s);
+
+// x0 / x / z / u may all be null: only the episode constants (y0s, masks) are rebuilt
+// 128 x 128 only: the whole stage (both transforms each way, the solve, the dual update) in one workgroup per slice
+hipError_t launch_admm_slice128(const float* x, float2* z, float2* u, const float2* tw, const float2* y0s,
+                                const uint8_t* masks, int mask_n, const float* mu, const float* tact, int N, hipStream_t s);
 
 // x0 / x / z / u may all be null: only the episode constants (y0s, masks) are rebuilt
 hipError_t launch_reset(const float2* x0, const float2* y0, const uint8_t* mask, int mask_n, float* x, float2* z,

@@ -212,8 +212,8 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
                 if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKP + (idx % PPP) * 4]) = raw[k][0];
             }
             __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
+#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: a real loop keeps the
+            for (int k = 0; k < NIT; ++k) {                // interpolation's temporaries out of the accumulators' way (no spills)
                 const int idx = tid + k * NT_;
                 const int part = idx % PPP, pp = idx / PPP;
                 const int py = pp / PWL, px = pp % PWL;

@@ -286,3 +286,44 @@ def test_denoiser_shape_sweep(sd_np, n, h, w, mode, monkeypatch):
     ref = O.denoise(sd, x, sigma, bf16_operands=(mode == "bf16"))
     # FLOAT TOLERANCE: f32 summation order (1e-5); bf16 operands: rounding flips reach the output at ~1e-3 (see above)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-3 if mode == "bf16" else 1e-5)
+
+
+def test_slice128_single_workgroup_stage_matches_three_launch_path_and_oracle(monkeypatch):
+    """128 x 128 (the reference's size): the whole data-fidelity stage in one workgroup per slice (admm_slice128_kernel:
+    one read, one write per slice) against the three-launch path (PNP_NO_SLICE128) and the oracle - per-slice mu, per-slice
+    masks, a stopped slice left untouched."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    n, h, w = 5, 128, 128
+    data = synthetic.make_problem(n, h, w, accel=4.0, seed=314)
+    rng = np.random.default_rng(3)
+    masks = torch.from_numpy(rng.random((n, h, w)) < 0.3)
+    x0 = torch.view_as_complex(torch.from_numpy(data["x0"]))
+    y0 = torch.view_as_complex(torch.from_numpy(data["y0"])) * masks.reshape(n, 1, h, w)
+    xr = torch.from_numpy((synthetic.hash_uniform(8, 1, n * h * w).reshape(n, 1, h, w) + 1) * 0.5)
+    u0 = torch.view_as_complex(torch.from_numpy(synthetic.hash_uniform(8, 2, n * h * w * 2).reshape(n, 1, h, w, 2) * 0.1))
+    mu = torch.tensor([0.05, 0.2, 0.4, 0.6, 0.9])
+    tact = torch.tensor([0.0, 0.0, 0.8, 0.0, 0.0])
+
+    def run(disable):
+        if disable:
+            monkeypatch.setenv("PNP_NO_SLICE128", "1")
+        else:
+            monkeypatch.delenv("PNP_NO_SLICE128", raising=False)
+        e = PnPEngine(n, h, w, denoiser=False)
+        _, z, u = e.reset(x0.cuda(), y0.cuda(), masks.cuda())
+        u.copy_(u0.cuda())
+        z0 = z.clone()
+        e.prox_dual(xr.cuda(), z, u, mu.cuda(), t_action=tact.cuda())
+        return z.cpu(), u.cpu(), z0.cpu()
+
+    z1, u1, zin = run(False)
+    z3, u3, _ = run(True)
+    # FLOAT TOLERANCE: same f32 butterflies in another order and exact 2^-7 scalings instead of two rsqrt(128) factors
+    assert float((z1 - z3).abs().max()) < 2e-6 and float((u1 - u3).abs().max()) < 2e-6
+    assert torch.equal(z1[2], zin[2]) and torch.equal(u1[2], u0[2])                       # stopped slice untouched
+    zf = O.fft2c(xr + u0)                                                                  # env.py:87-93 restated
+    temp = (mu.view(n, 1, 1, 1) * zf + y0) / (1 + mu.view(n, 1, 1, 1))
+    zo = O.ifft2c(torch.where(masks.reshape(n, 1, h, w), temp, zf))
+    uo = u0 + xr - zo
+    live = [0, 1, 3, 4]
+    assert float((z1[live] - zo[live]).abs().max()) < 3e-6 and float((u1[live] - uo[live]).abs().max()) < 3e-6
