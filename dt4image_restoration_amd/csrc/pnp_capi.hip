@@ -236,7 +236,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
 int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float* x, float2* z, float2* u,
                   hipStream_t s) {
     const int N = e->cfg.n, H = e->cfg.h, W = e->cfg.w;
-    if (H == 128 && W == 128 && !e->tune.no_slice128) {       // the reference's size: one workgroup per slice, 37 B/px
+    if (H == 128 && W == 128 && N >= e->tune.slice128_min_n) {   // chip-filling batches of the reference's slice size: 37 B/px
         Prof p(e, s, 4, -1);
         HIP_TRY(launch_admm_slice128(x, z, u, e->plan.tw_w, e->d_y0s, e->d_masks, e->mask_n, mu, tact, N, s));
         return PNP_OK;

@@ -18,7 +18,9 @@ struct Tuning {
     bool no_wino = false;         // PNP_NO_WINOGRAD
     int f4_min_cin = 64;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
-    bool no_slice128 = false;     // PNP_NO_SLICE128: 128 x 128 through the three-launch data-fidelity path (tests compare)
+    int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
+                                  // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
+                                  // needs a chip-filling batch to beat the three-launch path: 64.1 vs 78.8 us at 256 slices, 48.9 vs 34.9 at 64)
 };
 Tuning tuning_from_env();
 

@@ -290,8 +290,8 @@ def test_denoiser_shape_sweep(sd_np, n, h, w, mode, monkeypatch):
 
 def test_slice128_single_workgroup_stage_matches_three_launch_path_and_oracle(monkeypatch):
     """128 x 128 (the reference's size): the whole data-fidelity stage in one workgroup per slice (admm_slice128_kernel:
-    one read, one write per slice) against the three-launch path (PNP_NO_SLICE128) and the oracle - per-slice mu, per-slice
-    masks, a stopped slice left untouched."""
+    one read, one write per slice; default from 192 slices on, forced here with PNP_SLICE128_MIN_N) against the three-launch
+    path and the oracle - per-slice mu, per-slice masks, a stopped slice left untouched."""
     from dt4image_restoration_amd.engine import PnPEngine
     n, h, w = 5, 128, 128
     data = synthetic.make_problem(n, h, w, accel=4.0, seed=314)
@@ -305,10 +305,7 @@ def test_slice128_single_workgroup_stage_matches_three_launch_path_and_oracle(mo
     tact = torch.tensor([0.0, 0.0, 0.8, 0.0, 0.0])
 
     def run(disable):
-        if disable:
-            monkeypatch.setenv("PNP_NO_SLICE128", "1")
-        else:
-            monkeypatch.delenv("PNP_NO_SLICE128", raising=False)
+        monkeypatch.setenv("PNP_SLICE128_MIN_N", "100000" if disable else "1")
         e = PnPEngine(n, h, w, denoiser=False)
         _, z, u = e.reset(x0.cuda(), y0.cuda(), masks.cuda())
         u.copy_(u0.cuda())
