@@ -214,31 +214,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
     const int nskip = UP2 ? a.Cskip / CK : 0;              // leading chunks that come straight from the skip tensor
 
+    // Staging addresses are computed ONCE: every thread owns the same NIT patch items (pixel, 4 channels) in every chunk, so
+    // per chunk only the channel offset changes - a scalar (soffset of a buffer load).  Pixels outside the image (the conv's
+    // zero padding) and items past the patch get an out-of-range offset: the buffer's bounds check returns zeros, no
+    // per-item branches.  (f32 MFMAs run on the SIMD's vector issue port - exp/mfma_valu_coexec.hip - so every VALU
+    // instruction of the chunk loop is matrix time lost; the per-chunk index arithmetic used to cost as much as the input
+    // transform.)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0x80000000u;
+    const int cs = UP2 ? a.Cskip : a.Cin;
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.src0 + (size_t)n * a.H * a.W * cs), 0, a.H * a.W * cs * 4, 0x00020000);
+    unsigned voff[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = tid + k * NT_;
+        const int part = idx % PPP, pp = idx / PPP;
+        const int py = pp / PW, px = pp % PW;
+        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+        voff[k] = (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * cs + part * 4) * 4) : OOB;
+    }
+    const int Cup = a.Cin - a.Cskip;
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(UP2 ? a.src1 + (size_t)n * Hs * Ws * Cup : a.src0), 0, UP2 ? Hs * Ws * Cup * 4 : 0, 0x00020000);
+    unsigned voffL[UP2 ? NITL : 1];
+    if constexpr (UP2) {
+#pragma unroll
+        for (int k = 0; k < NITL; ++k) {
+            const int idx = tid + k * NT_;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int sy = ylo + pp / LW, sx = xlo + pp % LW;
+            voffL[k] = (idx < LITEMS && sy < Hs && sx < Ws) ? (unsigned)(((sy * Ws + sx) * Cup + part * 4) * 4) : OOB;
+        }
+    }
+    const int ldst = ((tid / PPP) * CKP + (tid % PPP) * 4);      // LDS slot of item 0; item k is k * (NT_ / PPP) pixels further
+
     float4 raw[NRAW];
     auto issue = [&](int c) {
         if (UP2 && c >= nskip) {                           // low-res region of an upsampled chunk
-            const int Cup = a.Cin - a.Cskip;
-            const float* base = a.src1 + (size_t)n * Hs * Ws * Cup + (c * CK - a.Cskip);
+            const int soff = (c * CK - a.Cskip) * 4;
 #pragma unroll
-            for (int k = 0; k < NITL; ++k) {
-                const int idx = tid + k * NT_;
-                const int part = idx % PPP, pp = idx / PPP;
-                const int sy = ylo + pp / LW, sx = xlo + pp % LW;
-                if (idx < LITEMS && sy < Hs && sx < Ws)
-                    raw[k] = *reinterpret_cast<const float4*>(base + ((size_t)sy * Ws + sx) * Cup + part * 4);
-            }
+            for (int k = 0; k < NITL; ++k)
+                raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, voffL[k], soff, 0));
             return;
         }
-        const int cs = UP2 ? a.Cskip : a.Cin;
+        const int soff = c * CK * 4;
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * NT_;
-            const int part = idx % PPP, pp = idx / PPP;
-            const int py = pp / PW, px = pp % PW;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                raw[k] = *reinterpret_cast<const float4*>(a.src0 + (((size_t)n * a.H + gy) * a.W + gx) * cs + c * CK + part * 4);
-        }
+        for (int k = 0; k < NIT; ++k)
+            raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
     };
     auto commit = [&](int c) {
         if (UP2 && c >= nskip) {
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
 #pragma unroll
             for (int k = 0; k < NITL; ++k) {
                 const int idx = tid + k * NT_;
-                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKP + (idx % PPP) * 4]) = raw[k];
+                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[ldst + k * (NT_ / PPP) * CKP]) = raw[k];
             }
             __syncthreads();
 #pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
@@ -277,14 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int idx = tid + k * NT_;
-            const int part = idx % PPP, pp = idx / PPP;
-            const int py = pp / PW, px = pp % PW;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = raw[k];
-                *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
-            }
+            if (idx < ITEMS) *reinterpret_cast<float4*>(&patch[ldst + k * (NT_ / PPP) * CKP]) = raw[k];
         }
     };
     issue(0);

@@ -212,8 +212,8 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_winograd_kernel(cons
                 if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKP + (idx % PPP) * 4]) = raw[k][0];
             }
             __syncthreads();
-#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: a real loop keeps the
-            for (int k = 0; k < NIT; ++k) {                // interpolation's temporaries out of the accumulators' way (no spills)
+#pragma unroll                                             // (kept unrolled: as a real loop it would not spill 6-20 registers, but
+            for (int k = 0; k < NIT; ++k) {                // measured 4 % slower on up4.conv-0: 1.502 vs 1.445 ms)
                 const int idx = tid + k * NT_;
                 const int part = idx % PPP, pp = idx / PPP;
                 const int py = pp / PWL, px = pp % PWL;
