@@ -15,8 +15,8 @@
 // (144 registers), two waves per SIMD.  Per 16-channel chunk:
 //   1. stage the (TH+2) x (TW+2) halo patch in LDS (loads of chunk c+1 in flight during chunk c's MFMAs; upsampled chunks
 //      come from the tile's low-res source region parked in LDS, like the F(2x2) kernel)
-//   2. input transform: thread (tile, 4 channels, quadrant) reads the 5x5 part of the 6x6 window its quadrant needs and
-//      writes the 9 frequency planes V[xi][tile][channel] its own wave pair consumes
+//   2. input transform: thread (tile, 2 channels, frequency-column group) reads the 6x5 part of the 6x6 window its three
+//      frequency columns need and writes their 18 frequency planes V[xi][tile][channel] (no value is computed twice)
 //   3. 36 independent GEMMs, 9 per wave: acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment, transformed
 //      weights streamed from L2 in pre-packed per-lane order)
 // Output transform: every wave turns its 3x3 block of M into a PARTIAL 4x4 output tile (lane-local), the four partials
@@ -60,61 +60,35 @@ __device__ __forceinline__ void bt3(const v2f* d, v2f* o) {
     }
 }
 
-// Column transform of window row y: three of the six outputs (QJ = 0: frequencies 0..2 from positions 0..4; QJ = 1: 3..5 from 1..5).
-template <int QJ, int PW, int CKP>
-__device__ __forceinline__ void wino4_row(const float* w, int y, v2f* cc) {
-    v2f d[6];
-    constexpr int X0 = QJ == 0 ? 0 : 1;
-    __builtin_amdgcn_sched_barrier(0);                 // one window row in flight at a time
-#pragma unroll
-    for (int x = 0; x < 5; ++x) d[X0 + x] = *reinterpret_cast<const v2f*>(w + (y * PW + X0 + x) * CKP);
-    bt3<QJ>(d, cc);
-}
-
-// The 3x3 block (rows 3QI.., columns 3QJ..) of V = B^T d B for one (tile, 2 channels): row by row - the column transform of
-// window row y, then its contribution B^T[i][y] to the three output rows (rows 0..4 feed QI = 0, rows 1..5 feed QI = 1).
-// (Two channels per item, not four: with 144 accumulator registers live the transform has ~70 registers to work in.)
-template <int QI, int QJ, int PW, int CKP, int PLANE>
+// V = B^T d B for one (tile, 2 channels) item and ONE column group (QJ = 0: frequency columns 0..2 from window positions
+// 0..4; QJ = 1: columns 3..5 from positions 1..5), all six frequency rows: the column transform of each of the six window
+// rows (three outputs), then the full six-point row transform of each of the three columns.  Nothing is computed twice
+// (84 packed VALU instructions and 30 + 18 LDS accesses per item; splitting the 36 frequencies by quadrant instead cost
+// 130 + 68 per thread because the two quadrant rows both transformed window rows 1..4).
+template <int QJ, int PW, int CKP, int PLANE>
 __device__ __forceinline__ void wino4_input_transform(const float* w, float* v) {
-    v2f o0[3], o1[3], o2[3], cc[3];
-    if constexpr (QI == 0) {
-        wino4_row<QJ, PW, CKP>(w, 0, cc);
+    constexpr int X0 = QJ == 0 ? 0 : 1;
+    v2f c[6][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) o0[j] = fK0 * cc[j];
-        wino4_row<QJ, PW, CKP>(w, 1, cc);
+    for (int y = 0; y < 6; ++y) {
+        v2f d[6];
+        __builtin_amdgcn_sched_barrier(0);                 // one window row in flight at a time (registers)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { o1[j] = -fAB2 * cc[j]; o2[j] = fAB2 * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 2, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] -= fK1 * cc[j]; o1[j] -= fB2 * cc[j]; o2[j] -= fB2 * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 3, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o1[j] += fA * cc[j]; o2[j] -= fA * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 4, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] += cc[j]; o1[j] += cc[j]; o2[j] += cc[j]; }
-    } else {
-        wino4_row<QJ, PW, CKP>(w, 1, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] = -fA2B * cc[j]; o1[j] = fA2B * cc[j]; o2[j] = fK0 * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 2, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] -= fA2 * cc[j]; o1[j] -= fA2 * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 3, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] += fB * cc[j]; o1[j] -= fB * cc[j]; o2[j] -= fK1 * cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 4, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] += cc[j]; o1[j] += cc[j]; }
-        wino4_row<QJ, PW, CKP>(w, 5, cc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) o2[j] += cc[j];
+        for (int x = 0; x < 5; ++x) d[X0 + x] = *reinterpret_cast<const v2f*>(w + (y * PW + X0 + x) * CKP);
+        bt3<QJ>(d, c[y]);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        *reinterpret_cast<v2f*>(v + (0 * 6 + j) * PLANE) = o0[j];
-        *reinterpret_cast<v2f*>(v + (1 * 6 + j) * PLANE) = o1[j];
-        *reinterpret_cast<v2f*>(v + (2 * 6 + j) * PLANE) = o2[j];
+        const v2f r0 = c[0][j], r1 = c[1][j], r2 = c[2][j], r3 = c[3][j], r4 = c[4][j], r5 = c[5][j];
+        float* vj = v + (3 * QJ + j) * PLANE;
+        *reinterpret_cast<v2f*>(vj + 0 * 6 * PLANE) = fK0 * r0 + (r4 - fK1 * r2);
+        const v2f e1 = r4 - fB2 * r2, o1 = fA * (r3 - fB2 * r1);
+        *reinterpret_cast<v2f*>(vj + 1 * 6 * PLANE) = e1 + o1;
+        *reinterpret_cast<v2f*>(vj + 2 * 6 * PLANE) = e1 - o1;
+        const v2f e2 = r4 - fA2 * r2, o2 = fB * (r3 - fA2 * r1);
+        *reinterpret_cast<v2f*>(vj + 3 * 6 * PLANE) = e2 + o2;
+        *reinterpret_cast<v2f*>(vj + 4 * 6 * PLANE) = e2 - o2;
+        *reinterpret_cast<v2f*>(vj + 5 * 6 * PLANE) = fK0 * r1 + (r5 - fK1 * r3);
     }
 }
 }  // namespace
@@ -180,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     constexpr int PF = 3;                              // B fragments in flight (must divide PAIRS: slots line up across chunks)
     constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
     static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
-    static_assert(PAIRS % PF == 0 && 16 * (CK / 2) * 4 == NT_ && 16 % TC == 0, "two (tile, 2-channel, quadrant) transform items per thread");
+    static_assert(PAIRS % PF == 0 && 32 * (CK / 2) * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKP]
@@ -305,14 +279,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     };
     issue(0);
 
-    // this thread's two transform items: tiles tq and tq + 16 of the workgroup's 32 tiles (TC per row), channels
-    // [2*hc, 2*hc+2), quadrant q (the quadrant its own wave pair consumes: tid / 128 == wid / 2).  Eight lanes cover a tile's
-    // 16 channels and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart: all 64 banks, conflict-free.
-    const int t7 = tid & 127;
-    const int hc = t7 & 7, tq = t7 >> 3;
+    // this thread's transform item: tile tq of the workgroup's 32 tiles (TC per row), channels [2*hc, 2*hc+2), frequency
+    // column group tj (waves 0-3: columns 0..2, waves 4-7: columns 3..5; all six rows).  Eight lanes cover a tile's 16 channels
+    // and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart: all 64 banks, conflict-free.
+    const int hc = tid & 7, tq = (tid >> 3) & 31;
+    const int tj = wid >> 2;
     const int win = ((4 * (tq / TC)) * PW + 4 * (tq % TC)) * CKP + 2 * hc;     // top-left of tile tq's 6x6 input window
-    constexpr int WIN16 = (4 * (16 / TC)) * PW * CKP;                          // ... of tile tq + 16: 16 / TC tile rows further down
-    const int vout = ((3 * qi) * 6 + 3 * qj) * PLANE + tq * CKP + 2 * hc;      // plane (3qi, 3qj) of item 0
+    const int vout = tq * CKP + 2 * hc;                                        // this item's slot in every frequency plane
 
     f32x16 acc[9];
 #pragma unroll
@@ -332,19 +305,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
         commit(c);
         __syncthreads();
 
-        // ---- input transform V = B^T d B, rows 3qi..3qi+2 and columns 3qj..3qj+2 (wave-uniform quadrant) --------------------
+        // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
         __builtin_amdgcn_sched_barrier(0);                 // keep the next chunk's loads (20 registers) behind the transform
-#pragma unroll 1
-        for (int it = 0; it < 2; ++it) {
-            const float* wsrc = patch + win + it * WIN16;
-            float* vdst = V + vout + it * 16 * CKP;
-            switch (q) {
-                case 0: wino4_input_transform<0, 0, PW, CKP, PLANE>(wsrc, vdst); break;
-                case 1: wino4_input_transform<0, 1, PW, CKP, PLANE>(wsrc, vdst); break;
-                case 2: wino4_input_transform<1, 0, PW, CKP, PLANE>(wsrc, vdst); break;
-                default: wino4_input_transform<1, 1, PW, CKP, PLANE>(wsrc, vdst); break;
-            }
-        }
+        if (tj == 0) wino4_input_transform<0, PW, CKP, PLANE>(patch + win, V + vout);
+        else wino4_input_transform<1, PW, CKP, PLANE>(patch + win, V + vout);
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) issue(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();

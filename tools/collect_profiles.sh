@@ -16,5 +16,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$G/pmcF$N" -o 
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$G/pmcW$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcW$N.err"
 echo "write done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$G/pmcS$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcS$N.err"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$G/pmcS$N" -o runc -- python3 "$R/bench.py" --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$G/pmcS$N.err"
 echo "sq done"

@@ -68,20 +68,27 @@ for r in rows:
 for d, (dur, name) in kt.items():
     agg[name.split("(")[0]]["dur_ns"] += dur
     cnt[name.split("(")[0]] += 1
-lines = ["| kernel | launches | avg us | clock GHz | MFMA busy / peak issue | WAIT_ANY | WAIT_INST_ANY | LDS bank conflict / SQ busy |",
-         "|---|---|---|---|---|---|---|---|"]
+lines = ["| kernel | launches | avg us | clock GHz | MFMA pipe busy | VALU issue busy (incl. MFMA issue) | LDS busy | bank-conflict share of LDS cycles | bank-conflict cycles / kernel cycles | WAIT_ANY | WAIT_INST_ANY |",
+         "|---|---|---|---|---|---|---|---|---|---|---|"]
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["dur_ns"]):
     if "conv3x3" not in k and "fft_" not in k:
         continue
     n = cnt[k]
     dur = v["dur_ns"] / n
     gui = v["GRBM_GUI_ACTIVE"] / n
-    lines.append("| %s | %d | %.0f | %.2f | %.3f | %.2f | %.2f | %.3f |" % (
-        k[5:], n, dur / 1e3, gui / 8 / dur, v["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (gui / 8 * 256 * 4),
-        v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
-        v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_BUSY_CYCLES"], 1)))
+    cyc = gui / 8                                     # kernel duration in core cycles (GRBM_GUI_ACTIVE sums the 8 XCDs)
+    lines.append("| %s | %d | %.0f | %.2f | %.3f | %.3f | %.3f | %.3f | %.3f | %.2f | %.2f |" % (
+        k[5:], n, dur / 1e3, cyc / dur, v["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (cyc * 256 * 4),
+        v["SQ_ACTIVE_INST_VALU"] * 4 / n / (cyc * 1024), v["SQ_LDS_IDX_ACTIVE"] / n / (cyc * 256),
+        v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_LDS_IDX_ACTIVE"], 1), v["SQ_LDS_BANK_CONFLICT"] / n / (cyc * 256),
+        v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]))
 open(f"{P}/{RND}_pmc_current.md", "w").write(
-    "# SQ counters of the conv kernels, current build (own rocprofv3 --pmc pass, bench.py --steps 2 --warmup 1)\n\n"
+    "# SQ counters of the conv and FFT kernels, current build (own rocprofv3 --pmc pass, bench.py --steps 2 --warmup 1 --reps 1)\n\n"
+    "Normalisation (per kernel launch, to the kernel's duration in core cycles = GRBM_GUI_ACTIVE / 8 XCDs): MFMA pipe busy = "
+    "SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs); VALU issue busy = SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs); LDS busy = "
+    "SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs); bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (the round-1 table "
+    "divided the conflict count, summed over all CUs, by SQ_BUSY_CYCLES, which is not per CU: those ratios of 0.65-0.88 were not "
+    "fractions of anything).\n\n"
     + "\n".join(lines) + f"\n\nHBM traffic of the conv kernels per step: {tf / 1e9:.2f} GB fetched (FETCH_SIZE x2) + {tw / 1e9:.2f} GB written.\n"
     f"HBM traffic of the three data-fidelity kernels per step: {ff / 1e6:.1f} MB fetched (FETCH_SIZE x2) + {fw / 1e6:.1f} MB written "
     f"(algorithmic: {37 * 64 * 256 * 256 / 1e6:.1f} MB; moved through L2: {81 * 64 * 256 * 256 / 1e6:.1f} MB).\n")
