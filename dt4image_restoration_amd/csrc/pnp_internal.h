@@ -87,6 +87,7 @@ struct WinoPlan {
     bool use;          // layer is eligible (long K, enough workgroups)
     int algo;          // 1: F(2x2,3x3) (winograd_kernels.hip), 4: F(4x4,3x3) (winograd4_kernels.hip)
     int tw, th, bn, wm, wn, ck, tiles_x, tiles_y;
+    int stack;         // F(4x4) on 16 x 16 images: two slices stacked into one 32-tile workgroup
 };
 // `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)
 WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t);

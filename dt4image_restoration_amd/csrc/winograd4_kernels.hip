@@ -136,13 +136,18 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst) {
         }
 }
 
-template <int TW, int SRC>
+// STK (TW = 16, SRC_PLAIN, 16 x 16 images only - the bottom level of a 256 x 256 slice): the workgroup's 32 tiles are the
+// 4 x 4 tiles of TWO consecutive slices stacked (tile rows 0..3 -> slice n0, 4..7 -> slice n0 + 1; two 18-row halo patches
+// one above the other), so the 32-tile M-block is full instead of half padding.
+template <int TW, int SRC, bool STK = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
     constexpr int CK = 16, CKP = CK + 4, PPP = CK / 4, NT_ = 512;
     constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
     constexpr int TH = 4 * TR;
-    constexpr int PH = TH + 2, PW = TW + 2;
+    constexpr int SUBH = STK ? TH / 2 + 2 : 0;         // rows of one slice's halo patch in the stacked layout
+    constexpr int PH = STK ? 2 * SUBH : TH + 2, PW = TW + 2;
     constexpr int ITEMS = PH * PW * PPP;
+    static_assert(!STK || (TW == 16 && SRC == SRC_PLAIN), "stacked slices: 16-wide tiles, plain source");
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr bool UP2 = SRC == SRC_UPCAT;
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
@@ -174,12 +179,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     const int grp = bid / (8 * ny), rem = bid % (8 * ny);
     const int cby = rem >> 3;                              // this workgroup's 64-channel block
     int bt = grp * 8 + (rem & 7);                          // spatial tile index
-    if (bt >= a.tilesX * a.tilesY * a.N) return;
+    if (bt >= a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N)) return;
     const int tx0 = (bt % a.tilesX) * TW;
     bt /= a.tilesX;
     const int ty0 = (bt % a.tilesY) * TH;
-    const int n = bt / a.tilesY;
-    if (a.tact != nullptr && a.tact[n] > 0.5f) return;
+    const int n = STK ? 2 * (bt / a.tilesY) : bt / a.tilesY;               // first (or only) slice of this workgroup
+    const int nsl = STK ? (n + 1 < a.N ? 2 : 1) : 1;                       // slices this workgroup holds
+    const bool live0 = !(a.tact != nullptr && a.tact[n] > 0.5f);
+    const bool live1 = STK && nsl == 2 && !(a.tact != nullptr && a.tact[n + 1] > 0.5f);
+    if (!live0 && !live1) return;
     const int cb = cby * 2 + cg;                           // this wave's 32-channel block
     const int nchunks = a.Cin / CK;
 
@@ -198,15 +206,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     constexpr unsigned OOB = 0x80000000u;
     const int cs = UP2 ? a.Cskip : a.Cin;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.src0 + (size_t)n * a.H * a.W * cs), 0, a.H * a.W * cs * 4, 0x00020000);
+        (void*)(a.src0 + (size_t)n * a.H * a.W * cs), 0, nsl * a.H * a.W * cs * 4, 0x00020000);
     unsigned voff[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int idx = tid + k * NT_;
         const int part = idx % PPP, pp = idx / PPP;
         const int py = pp / PW, px = pp % PW;
-        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-        voff[k] = (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * cs + part * 4) * 4) : OOB;
+        const int sub = STK ? py / SUBH : 0;                               // stacked: which of the two slices
+        const int gy = STK ? py % SUBH - 1 : ty0 + py - 1, gx = tx0 + px - 1;
+        voff[k] = (idx < ITEMS && sub < nsl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                      ? (unsigned)((((sub * a.H + gy) * a.W + gx) * cs + part * 4) * 4) : OOB;
     }
     const int Cup = a.Cin - a.Cskip;
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -284,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     // and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart: all 64 banks, conflict-free.
     const int hc = tid & 7, tq = (tid >> 3) & 31;
     const int tj = wid >> 2;
-    const int win = ((4 * (tq / TC)) * PW + 4 * (tq % TC)) * CKP + 2 * hc;     // top-left of tile tq's 6x6 input window
+    const int trow = tq / TC;                                                  // tile row; stacked: rows 0..3 / 4..7 = slice 0 / 1
+    const int wrow = STK ? (trow / (TR / 2)) * SUBH + 4 * (trow % (TR / 2)) : 4 * trow;
+    const int win = (wrow * PW + 4 * (tq % TC)) * CKP + 2 * hc;                // top-left of tile tq's 6x6 input window
     const int vout = tq * CKP + 2 * hc;                                        // this item's slot in every frequency plane
 
     f32x16 acc[9];
@@ -386,7 +398,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
         // reduce + finish: tile t = rr + 8g + 4hh of the M-block, window (wy, wx) of its 4x4 pixels
         {
             const int t = r_rr + 8 * g + 4 * r_hh;
-            const int py = 4 * (t / TC) + 2 * (r_w >> 1), px = 4 * (t % TC) + 2 * (r_w & 1);
+            const int tr = t / TC;
+            const int sub = STK ? tr / (TR / 2) : 0;                        // stacked: the slice this tile belongs to
+            const bool live = STK ? (sub == 0 ? live0 : live1) : true;
+            const int py = (STK ? 4 * (tr % (TR / 2)) : 4 * tr) + 2 * (r_w >> 1), px = 4 * (t % TC) + 2 * (r_w & 1);
             const float* pr = P + (((r_cg * 4) * 4 + r_rr) * 16) * 64 + r_hh * 32 + 4 * r_c4;
             float4 o[4];
 #pragma unroll
@@ -398,13 +413,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
                 s = f4add(s, bias4);
                 o[e] = make_float4(fmaxf(s.x, kLeaky * s.x), fmaxf(s.y, kLeaky * s.y), fmaxf(s.z, kLeaky * s.z), fmaxf(s.w, kLeaky * s.w));
                 const int gy = ty0 + py + (e >> 1), gx = tx0 + px + (e & 1);
-                if (gy < a.H && gx < a.W)
-                    *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cout0) = o[e];
+                if (live && gy < a.H && gx < a.W)
+                    *reinterpret_cast<float4*>(a.dst + (((size_t)(n + sub) * a.H + gy) * a.W + gx) * a.Cout + cout0) = o[e];
             }
             if (a.pooled != nullptr) {                     // MaxPool2d(2) of this window for the next stage (noise.py:22-25)
                 const int gy = (ty0 + py) >> 1, gx = (tx0 + px) >> 1;
-                if (gy < Hp && gx < Wp)
-                    *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * a.Cout + cout0) =
+                if (live && gy < Hp && gx < Wp)
+                    *reinterpret_cast<float4*>(a.pooled + (((size_t)(n + sub) * Hp + gy) * Wp + gx) * a.Cout + cout0) =
                         f4max(f4max(o[0], o[1]), f4max(o[2], o[3]));
             }
         }
@@ -412,17 +427,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     (void)V4;
 }
 
-template <int TW, int SRC>
+template <int TW, int SRC, bool STK = false>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
     constexpr int CKP = 20, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
-    constexpr size_t lds_main = ((size_t)(TH + 2) * (TW + 2) + 36 * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * CKP * sizeof(float);
+    constexpr size_t lds_main = ((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) + 36 * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * CKP * sizeof(float);
     constexpr size_t lds_out = (size_t)2 * 4 * 4 * 16 * 64 * sizeof(float);
     constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
-    auto kern = conv3x3_wino4_kernel<TW, SRC>;
+    auto kern = conv3x3_wino4_kernel<TW, SRC, STK>;
     static DeviceOnce cap;
     if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
-    const int ntiles = p.tiles_x * p.tiles_y * a.N, ny = a.Cout / 64;
+    const int ntiles = p.tiles_x * p.tiles_y * (STK ? (a.N + 1) / 2 : a.N), ny = a.Cout / 64;
     dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * ny));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
     return hipGetLastError();
@@ -438,6 +453,7 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
         if (src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN>(a, p, s);
         if (src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT>(a, p, s);
     } else if (p.tw == 16) {
+        if (p.stack) return src_mode == SRC_PLAIN && a.H == 16 && a.W == 16 ? launch_wino4_inst<16, SRC_PLAIN, true>(a, p, s) : hipErrorInvalidValue;
         if (src_mode == SRC_PLAIN) return launch_wino4_inst<16, SRC_PLAIN>(a, p, s);
         if (src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT>(a, p, s);
     }

@@ -395,3 +395,26 @@ def test_interleaved_episodes_on_one_denoiser(denoiser):
         sc, _ = env_a.step(sc, act)
     for k in ref_a:
         assert torch.equal(sc[k], ref_a[k]), k
+
+
+def test_stopped_slice_in_a_stacked_workgroup_is_untouched(denoiser):
+    """At 256 x 256 the 16 x 16 bottom level runs F(4x4) with TWO slices per workgroup; a slice that has stopped must stay
+    bit-identical while its workgroup mate advances exactly as it does without the stop."""
+    data = synthetic.make_problem(4, 256, 256, seed=71)
+    mu = torch.tensor([0.1, 0.2, 0.3, 0.4]); sg = torch.tensor([0.05, 0.08, 0.1, 0.12])
+
+    def run(stop):
+        env = _env(denoiser)
+        st = env.reset(_mat(data), "cuda")
+        st, _ = env.step(st, {"T": torch.zeros(4), "mu": mu, "sigma_d": sg})
+        before = {k: st[k].clone() for k in ("x", "z", "u")}
+        st, done = env.step(st, {"T": torch.tensor([0.0, 0.9 if stop else 0.0, 0.0, 0.0]), "mu": mu, "sigma_d": sg})
+        return before, {k: st[k].clone() for k in ("x", "z", "u")}, done
+
+    b1, a1, d1 = run(True)
+    b0, a0, d0 = run(False)
+    assert d1.tolist() == [False, True, False, False] and not bool(d0.any())
+    for k in ("x", "z", "u"):
+        assert torch.equal(a1[k][1], b1[k][1])                       # the stopped slice
+        for i in (0, 2, 3):
+            assert torch.equal(a1[k][i], a0[k][i]), (k, i)           # its workgroup mate (slice 0) and the others

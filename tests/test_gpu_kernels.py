@@ -181,7 +181,8 @@ def test_winograd_path_matches_oracle_per_stage(sd_np, n, h, w, monkeypatch):
     np.testing.assert_allclose(got.cpu().numpy(), torch.clamp(ref_raw, 0, 1).numpy(), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,h,w,min_cin", [(2, 128, 128, 128), (2, 96, 112, 128), (1, 144, 64, 128), (1, 256, 256, 128), (3, 128, 64, 64)])
+@pytest.mark.parametrize("n,h,w,min_cin", [(2, 128, 128, 128), (2, 96, 112, 128), (1, 144, 64, 128), (1, 256, 256, 128), (3, 128, 64, 64),
+                                           (3, 256, 256, 64)])      # 16 x 16 bottom level: two slices stacked per workgroup (odd batch)
 def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, monkeypatch):
     """F(4x4,3x3) (winograd4_kernels.hip, points 0, +-3/4, +-3/2, inf) on every layer it can take - workgroup gate lifted so
     small and ragged sizes run it (partial 4x4 tiles, 16- and 32-wide tile variants, upsample+concat sources, pooled copies
