@@ -113,7 +113,9 @@ def greedy_leg(args, dev, sd_np, n, h, w, world):
     model = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
     model.load_state_dict(weights.generate_policy_weights(model, 7, t_bias=-8.0, head_gain=1.0))
     den = UNetDenoiser2D(state_dict=sd_np, bf16_convs=args.convs == "bf16")
-    ev = GreedyEvaluator(model, PnPEnv(args.steps, den, dev), max_timesteps=args.steps, device_type=dev, sync_every=10)
+    # the policy's time embedding has 30 entries (decision_transformer.py:283 max_timestep): a DT-driven episode is at most 30 steps
+    ep_steps = min(args.steps, model.time_embed.num_embeddings)
+    ev = GreedyEvaluator(model, PnPEnv(ep_steps, den, dev), max_timesteps=ep_steps, device_type=dev, sync_every=10)
     total = n * world
     shard = {}
 

@@ -63,6 +63,11 @@ class GreedyEvaluator:
         self.model = model.to(device_type).eval()
         self.env = env
         self.action_dim = action_dim
+        horizon = getattr(getattr(model, "time_embed", None), "num_embeddings", None)
+        if horizon is not None and max_timesteps > horizon:
+            # (on the GPU an out-of-range time step would be a device-side assert in the embedding lookup: the process aborts)
+            raise ValueError(f"max_timesteps={max_timesteps} exceeds the policy's time embedding ({horizon} steps, "
+                             f"decision_transformer.py:283 max_timestep)")
         self.max_timesteps = max_timesteps
         self.context_length = block_size // 3
         self.device = torch.device(device_type)

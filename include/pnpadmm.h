@@ -166,9 +166,9 @@ int pnp_profile_collect(pnp_handle h, double* total_ms, int64_t* launches);
 /* per-conv-layer totals (28 entries, execution order); handles created with PNP_FLAG_PROFILE_LAYERS only */
 int pnp_profile_layers(pnp_handle h, double* layer_ms, int64_t* layer_launches);
 
-/* Which kernel each of the 28 conv layers runs on for this handle's problem size (valid after
- * pnp_load_unet_weights): 0 direct MFMA conv, 1 Winograd F(2x2,3x3) MFMA conv (executes 16/36 of the direct
- * multiplies), 2 VALU first layer, 3 last layer (fused into layer 26's epilogue or its own kernel). */
+/* Which kernel each of the 28 conv layers runs on for this handle's problem size (fixed at pnp_create):
+ * 0 direct MFMA conv, 1 Winograd F(2x2,3x3) MFMA conv (executes 16/36 of the direct multiplies), 4 Winograd F(4x4,3x3)
+ * MFMA conv (36/144), 2 VALU first layer, 3 last layer (fused into layer 26's epilogue or its own kernel). */
 int pnp_conv_algorithms(pnp_handle h, int32_t* algo28);
 
 /* Engine workspace size in bytes (device memory owned by the handle). */
