@@ -220,7 +220,8 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         {
             Prof p(e, s, 0, 26, per_layer);
             ++run_launches;
-            if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[26], SRC_PLAIN, s));
+            if (e->wino[26] && e->wplan[26].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[26], SRC_PLAIN, s));
+            else if (e->wino[26]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[26], SRC_PLAIN, s));
             else HIP_TRY(launch_conv3x3(a, e->cplan[26], SRC_PLAIN, s));
         }
         run.end(run_launches);
@@ -295,6 +296,14 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             if (L.src == SRC_POOL && (lh * 2) % 2 == 0 && (e->wino[li - 1] || conv3x3_pooled_output_ok(e->cplan[li - 1])))
                 src_mode = SRC_PLAIN;
             e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, e->tune);
+            if (li == 26 && e->wplan[li].algo == 4 && !(cfg->flags & PNP_FLAG_KEEP_STAGES)) {
+                // up4.conv-2 carries the fused last layer (1x1 conv + residual + clamp) in its epilogue: the F(2x2) kernel walks
+                // whole pixels there (coalesced 4-byte stores); the F(4x4) epilogue's (window, 4 channels) ownership needs a
+                // cross-lane reduction per pixel and measured 0.582 against 0.489 ms
+                Tuning t2 = e->tune;
+                t2.no_f4 = true;
+                e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, t2);
+            }
             e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16);
             e->wino[li] = e->wplan[li].use && !bf16;
             if (e->wino[li]) continue;
@@ -403,7 +412,7 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
             } else if (e->wino[li] && e->wplan[li].algo == 4) {
                 pf = winograd4_pack_floats(L.cin, L.cout);
                 tmp.assign(pf, 0.f);
-                pack_winograd4_weights(w, L.cin, L.cout, tmp.data());
+                pack_winograd4_weights(w, L.cin, L.cout, e->wplan[li].ck, tmp.data());
                 src = tmp.data();
             } else if (e->wino[li]) {
                 pf = winograd_pack_floats(L.cin, L.cout);

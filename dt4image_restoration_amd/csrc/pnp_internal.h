@@ -16,7 +16,7 @@ struct Tuning {
     bool wino_big = false;        // PNP_WINO_BIG_GROUPS: the 8-wave plans everywhere
     bool wino_small = false;      // PNP_WINO_SMALL_GROUPS
     bool no_wino = false;         // PNP_NO_WINOGRAD
-    int f4_min_cin = 64;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
+    int f4_min_cin = 32;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
@@ -92,7 +92,7 @@ struct WinoPlan {
 // `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)
 WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t);
 size_t winograd4_pack_floats(int cin, int cout);
-void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst);
+void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float* dst);
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s);
 size_t winograd_pack_floats(int cin, int cout);
 void pack_winograd_weights(const float* oihw, int cin, int cout, int ck, float* dst);

@@ -96,8 +96,8 @@ __device__ __forceinline__ void wino4_input_transform(const float* w, float* v) 
 // ---- host: U = G g G^T (6x6 per (cout, cin)), packed [cout/32][quadrant 4][chunk][ks 2][k 9][lane 64][4] -----------------
 size_t winograd4_pack_floats(int cin, int cout) { return (size_t)(cout / 32) * ((size_t)(cin / 8) * 36 * 256 + 4 * 4 * 256); }
 
-void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst) {
-    constexpr int CK = 16;
+void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float* dst) {
+    const int CK = ck;                                  // 16 (64-channel workgroups) or 8 (32-channel workgroups)
     // G rows: p^k / N_p for the finite points, [0 0 1] for infinity; N_p = prod_{q != p} (p - q)
     const double pts[5] = {0.0, kA, -kA, kB, -kB};
     double G[6][3];
@@ -139,15 +139,20 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, float* dst) {
 // STK (TW = 16, SRC_PLAIN, 16 x 16 images only - the bottom level of a 256 x 256 slice): the workgroup's 32 tiles are the
 // 4 x 4 tiles of TWO consecutive slices stacked (tile rows 0..3 -> slice n0, 4..7 -> slice n0 + 1; two 18-row halo patches
 // one above the other), so the 32-tile M-block is full instead of half padding.
-template <int TW, int SRC, bool STK = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
-    constexpr int CK = 16, CKP = CK + 4, PPP = CK / 4, NT_ = 512;
+// WN = 2: 8 waves, 64 output channels, 16-channel chunks, one workgroup per CU (the layout described above).
+// WN = 1 (Cout = 32, the full-resolution layers): 4 waves = the 4 quadrants of ONE 32-channel group, 8-channel chunks, and the
+// LDS cut to 79.8 KB (patch pixel stride 10 floats instead of 12) so that TWO workgroups share a CU.
+template <int TW, int SRC, bool STK = false, int WN = 2>
+__global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
+    constexpr int CK = 8 * WN, CKP = CK + 4, PPP = CK / 4, NT_ = 256 * WN;
+    constexpr int CKQ = WN == 2 ? CK + 4 : CK + 2;     // patch pixel stride (floats): b64 window reads conflict-free for both
+    constexpr int HCN = CK / 2;                        // 2-channel units per pixel
     constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
     constexpr int TH = 4 * TR;
     constexpr int SUBH = STK ? TH / 2 + 2 : 0;         // rows of one slice's halo patch in the stacked layout
     constexpr int PH = STK ? 2 * SUBH : TH + 2, PW = TW + 2;
     constexpr int ITEMS = PH * PW * PPP;
-    static_assert(!STK || (TW == 16 && SRC == SRC_PLAIN), "stacked slices: 16-wide tiles, plain source");
+    static_assert(!STK || (TW == 16 && SRC == SRC_PLAIN && WN == 2), "stacked slices: 16-wide tiles, plain source");
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr bool UP2 = SRC == SRC_UPCAT;
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
@@ -159,25 +164,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     constexpr int PF = 3;                              // B fragments in flight (must divide PAIRS: slots line up across chunks)
     constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
     static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
-    static_assert(PAIRS % PF == 0 && 32 * (CK / 2) * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
+    static_assert(PAIRS % PF == 0 && 32 * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
+    static_assert(LH * LW * CKP <= 36 * PLANE, "the low-res region is parked in V's space");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const patch = smem;                             // [PH][PW][CKP]
-    float* const V = smem + PH * PW * CKP;                 // [36][32 tiles][CKP]
-    float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][CKP] low-res source region
-
+    float* const patch = smem;                             // [PH][PW][CKQ]
+    float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][32 tiles][CKP]
+    float* const lowres = V;                               // UPCAT: [LH][LW][CKP] low-res source region; V is dead while a
+                                                           // chunk is staged (between the loop-top barrier and the transform)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = wid >> 1, cg = wid & 1;                  // frequency quadrant, 32-channel group of this wave
+    const int q = wid / WN, cg = wid % WN;                 // frequency quadrant, 32-channel group of this wave
     const int qi = q >> 1, qj = q & 1;
     const int hh = lane >> 5, li = lane & 31;
 
     // XCD-aware decode: the channel groups of one spatial tile run back to back on the same XCD (blocks b and b + 8 share
     // an XCD under round-robin placement - speed only), so the patch they all read is fetched into that L2 once.
-    const int ny = a.Cout >> 6;
+    const int ny = a.Cout / (32 * WN);
     const int bid = blockIdx.x;
     const int grp = bid / (8 * ny), rem = bid % (8 * ny);
-    const int cby = rem >> 3;                              // this workgroup's 64-channel block
+    const int cby = rem >> 3;                              // this workgroup's block of 32 * WN channels
     int bt = grp * 8 + (rem & 7);                          // spatial tile index
     if (bt >= a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N)) return;
     const int tx0 = (bt % a.tilesX) * TW;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     const bool live0 = !(a.tact != nullptr && a.tact[n] > 0.5f);
     const bool live1 = STK && nsl == 2 && !(a.tact != nullptr && a.tact[n + 1] > 0.5f);
     if (!live0 && !live1) return;
-    const int cb = cby * 2 + cg;                           // this wave's 32-channel block
+    const int cb = cby * WN + cg;                          // this wave's 32-channel block
     const int nchunks = a.Cin / CK;
 
     const int Hs = a.H >> 1, Ws = a.W >> 1;
@@ -231,7 +237,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
             voffL[k] = (idx < LITEMS && sy < Hs && sx < Ws) ? (unsigned)(((sy * Ws + sx) * Cup + part * 4) * 4) : OOB;
         }
     }
-    const int ldst = ((tid / PPP) * CKP + (tid % PPP) * 4);      // LDS slot of item 0; item k is k * (NT_ / PPP) pixels further
+    const int ldst = ((tid / PPP) * CKQ + (tid % PPP) * 4);      // patch slot of item 0; item k is k * (NT_ / PPP) pixels further
+    const int ldstL = ((tid / PPP) * CKP + (tid % PPP) * 4);     // the same in the low-res region (pixel stride CKP)
+    auto put_patch = [&](int off, float4 v) {              // pixel stride 10 floats (WN = 1) is only 8-byte aligned
+        if constexpr (CKQ % 4 == 0) *reinterpret_cast<float4*>(&patch[off]) = v;
+        else { *reinterpret_cast<float2*>(&patch[off]) = make_float2(v.x, v.y); *reinterpret_cast<float2*>(&patch[off + 2]) = make_float2(v.z, v.w); }
+    };
 
     float4 raw[NRAW];
     auto issue = [&](int c) {
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
 #pragma unroll
             for (int k = 0; k < NITL; ++k) {
                 const int idx = tid + k * NT_;
-                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[ldst + k * (NT_ / PPP) * CKP]) = raw[k];
+                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[ldstL + k * (NT_ / PPP) * CKP]) = raw[k];
             }
             __syncthreads();
 #pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
                                     *reinterpret_cast<const float4*>(r1 + x0 * CKP), *reinterpret_cast<const float4*>(r1 + x1 * CKP),
                                     1.f - lx, lx, 1.f - ly, ly);
                     }
-                    *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;
+                    put_patch((py * PW + px) * CKQ + part * 4, v);
                 }
             }
             return;
@@ -284,19 +295,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int idx = tid + k * NT_;
-            if (idx < ITEMS) *reinterpret_cast<float4*>(&patch[ldst + k * (NT_ / PPP) * CKP]) = raw[k];
+            if (idx < ITEMS) put_patch(ldst + k * (NT_ / PPP) * CKQ, raw[k]);
         }
     };
     issue(0);
 
     // this thread's transform item: tile tq of the workgroup's 32 tiles (TC per row), channels [2*hc, 2*hc+2), frequency
-    // column group tj (waves 0-3: columns 0..2, waves 4-7: columns 3..5; all six rows).  Eight lanes cover a tile's 16 channels
-    // and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart: all 64 banks, conflict-free.
-    const int hc = tid & 7, tq = (tid >> 3) & 31;
-    const int tj = wid >> 2;
+    // column group tj (first half of the waves: columns 0..2, second half: columns 3..5; all six rows).  HCN lanes cover a
+    // tile's channels and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart (WN = 2) or 8 tiles 40 floats apart
+    // (WN = 1): all 64 banks, conflict-free.
+    const int hc = tid % HCN, tq = (tid / HCN) & 31;
+    const int tj = wid / (2 * WN);
     const int trow = tq / TC;                                                  // tile row; stacked: rows 0..3 / 4..7 = slice 0 / 1
     const int wrow = STK ? (trow / (TR / 2)) * SUBH + 4 * (trow % (TR / 2)) : 4 * trow;
-    const int win = (wrow * PW + 4 * (tq % TC)) * CKP + 2 * hc;                // top-left of tile tq's 6x6 input window
+    const int win = (wrow * PW + 4 * (tq % TC)) * CKQ + 2 * hc;                // top-left of tile tq's 6x6 input window
     const int vout = tq * CKP + 2 * hc;                                        // this item's slot in every frequency plane
 
     f32x16 acc[9];
@@ -319,8 +331,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
 
         // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
         __builtin_amdgcn_sched_barrier(0);                 // keep the next chunk's loads (20 registers) behind the transform
-        if (tj == 0) wino4_input_transform<0, PW, CKP, PLANE>(patch + win, V + vout);
-        else wino4_input_transform<1, PW, CKP, PLANE>(patch + win, V + vout);
+        if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);
+        else wino4_input_transform<1, PW, CKQ, PLANE>(patch + win, V + vout);
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) issue(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();
@@ -353,8 +365,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     // thread (cg, rr, hh, 2x2 window, 4 channels) sums the four quadrants in the order q = 0..3 and finishes the pixels.
     float* const P = smem;
     constexpr int V4 = 8;                                   // float4 per 32-channel group
-    const int r_c4 = tid & 7, r_cg = (tid >> 3) & 1, r_hh = (tid >> 4) & 1, r_w = (tid >> 5) & 3, r_rr = tid >> 7;
-    const int cout0 = cby * 64 + r_cg * 32 + 4 * r_c4;
+    constexpr int CGB = WN == 2 ? 1 : 0;                   // bits of the channel-group field in the reducer's thread index
+    const int r_c4 = tid & 7, r_cg = (tid >> 3) & (WN - 1), r_hh = (tid >> (3 + CGB)) & 1, r_w = (tid >> (4 + CGB)) & 3,
+              r_rr = tid >> (6 + CGB);
+    const int cout0 = cby * (32 * WN) + r_cg * 32 + 4 * r_c4;
     const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + cout0);
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     // one-dimensional partial output transform of three values (the quadrant's rows or columns) into four
@@ -413,6 +427,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
                 s = f4add(s, bias4);
                 o[e] = make_float4(fmaxf(s.x, kLeaky * s.x), fmaxf(s.y, kLeaky * s.y), fmaxf(s.z, kLeaky * s.z), fmaxf(s.w, kLeaky * s.w));
                 const int gy = ty0 + py + (e >> 1), gx = tx0 + px + (e & 1);
+                if constexpr (WN == 1) {
+                    if (a.last_w != nullptr) {
+                        // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp.  The eight
+                        // threads c4 = 0..7 of a pixel hold its 32 channels: partial dot products, xor-shuffled together; this
+                        // conv's own 32-channel output is never written.
+                        const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * r_c4);
+                        float dsum = o[e].x * wv.x + o[e].y * wv.y + o[e].z * wv.z + o[e].w * wv.w;
+                        dsum += __shfl_xor(dsum, 1); dsum += __shfl_xor(dsum, 2); dsum += __shfl_xor(dsum, 4);
+                        if (r_c4 == 0 && gy < a.H && gx < a.W) {
+                            const size_t qx = ((size_t)n * a.H + gy) * a.W + gx;
+                            const float img = a.last_ximg != nullptr ? a.last_ximg[qx] : (a.last_z[qx].x - a.last_u[qx].x);
+                            a.last_out[qx] = fminf(fmaxf(img + dsum + a.last_b[0], 0.f), 1.f);
+                        }
+                        continue;
+                    }
+                }
                 if (live && gy < a.H && gx < a.W)
                     *reinterpret_cast<float4*>(a.dst + (((size_t)(n + sub) * a.H + gy) * a.W + gx) * a.Cout + cout0) = o[e];
             }
@@ -427,28 +457,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(const ConvArgs a)
     (void)V4;
 }
 
-template <int TW, int SRC, bool STK = false>
+template <int TW, int SRC, bool STK = false, int WN = 2>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
-    constexpr int CKP = 20, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
-    constexpr size_t lds_main = ((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) + 36 * 32 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) : 0)) * CKP * sizeof(float);
-    constexpr size_t lds_out = (size_t)2 * 4 * 4 * 16 * 64 * sizeof(float);
+    constexpr int CK = 8 * WN, CKP = CK + 4, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
+    constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
+    constexpr size_t lds_main = (patch_f + (size_t)36 * 32 * CKP) * sizeof(float);
+    constexpr size_t lds_out = (size_t)WN * 4 * 4 * 16 * 64 * sizeof(float);
     constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
-    static_assert(lds <= 160 * 1024, "one workgroup per CU");
-    auto kern = conv3x3_wino4_kernel<TW, SRC, STK>;
+    static_assert(lds <= (WN == 2 ? 160 : 80) * 1024, "one (WN = 2) / two (WN = 1) workgroups per CU");
+    auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN>;
     static DeviceOnce cap;
     if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
-    const int ntiles = p.tiles_x * p.tiles_y * (STK ? (a.N + 1) / 2 : a.N), ny = a.Cout / 64;
+    const int ntiles = p.tiles_x * p.tiles_y * (STK ? (a.N + 1) / 2 : a.N), ny = a.Cout / (32 * WN);
     dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * ny));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * WN), lds, s, a);
     return hipGetLastError();
 }
 
 // `a.wpack` must be the F(4x4) pack (pack_winograd4_weights).
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
-    if (!p.use || p.algo != 4 || a0.Cout % 64 || a0.Cin % 16 || (src_mode == SRC_UPCAT && a0.Cskip % 16)) return hipErrorInvalidValue;
+    if (!p.use || p.algo != 4 || a0.Cout % p.bn || a0.Cin % p.ck || (src_mode == SRC_UPCAT && a0.Cskip % p.ck)) return hipErrorInvalidValue;
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
+    if (p.bn == 32) {                                      // Cout = 32: 4-wave workgroups, 8-channel chunks, two per CU
+        if (p.ck != 8 || p.stack) return hipErrorInvalidValue;
+        if (p.tw == 32 && src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN, false, 1>(a, p, s);
+        if (p.tw == 32 && src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT, false, 1>(a, p, s);
+        if (p.tw == 16 && src_mode == SRC_PLAIN) return launch_wino4_inst<16, SRC_PLAIN, false, 1>(a, p, s);
+        if (p.tw == 16 && src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT, false, 1>(a, p, s);
+        return hipErrorInvalidValue;
+    }
+    if (a.last_w != nullptr || p.ck != 16) return hipErrorInvalidValue;
     if (p.tw == 32) {
         if (src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN>(a, p, s);
         if (src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT>(a, p, s);

@@ -78,16 +78,18 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
     // F(4x4,3x3) (winograd4_kernels.hip): 1.78x fewer MFMAs again where the matrix pipe is the bound - Cin >= 64 (measured: +10 % at 64, +21..30 % at 128..768),
     // 64-channel output blocks, 32 tiles of 4x4 pixels per workgroup (16 x 32 or 32 x 16 pixels), so the image must be at
     // least that large in the tile's long direction - or 16 x 16 exactly, where two slices are stacked into one workgroup.
-    if (!t.no_f4 && Cin >= t.f4_min_cin && Cout % 64 == 0 && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
+    if (!t.no_f4 && Cin >= t.f4_min_cin && (Cout % 64 == 0 || Cout == 32) && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
         W >= 16 && H >= 16 && (W >= 32 || H >= 32 || (W == 16 && H == 16 && src_mode == SRC_PLAIN && N >= 2))) {
         WinoPlan f{};
         f.algo = 4;
         f.tw = W >= 32 ? 32 : 16;
         f.th = f.tw == 32 ? 16 : 32;
         f.bn = 64; f.wm = 1; f.wn = 2; f.ck = 16;
+        if (Cout == 32) { f.bn = 32; f.wn = 1; f.ck = 8; }  // 4-wave workgroups (one 32-channel group), two per CU
         f.tiles_x = (W + f.tw - 1) / f.tw;
         f.tiles_y = (H + f.th - 1) / f.th;
         f.stack = (W == 16 && H == 16) ? 1 : 0;             // 16 x 16 images: two slices per 32-tile workgroup
+        if (f.stack && Cout == 32) return p;
         const long blocks = (long)f.tiles_x * f.tiles_y * (f.stack ? (N + 1) / 2 : N) * (Cout / f.bn);
         f.use = blocks >= t.wino_min_blocks;
         if (f.use) return f;

@@ -43,7 +43,7 @@ int main() {
                     CHECK(wp.tiles_x * wp.tw >= wd && wp.tiles_y * wp.th >= h && L.cin % wp.ck == 0);
                     const size_t pf = wp.algo == 4 ? winograd4_pack_floats(L.cin, L.cout) : winograd_pack_floats(L.cin, L.cout);
                     float* dst = (float*)std::malloc(pf * sizeof(float));          // exact size: redzones right behind it
-                    if (wp.algo == 4) pack_winograd4_weights(w.data(), L.cin, L.cout, dst);
+                    if (wp.algo == 4) pack_winograd4_weights(w.data(), L.cin, L.cout, wp.ck, dst);
                     else pack_winograd_weights(w.data(), L.cin, L.cout, wp.ck, dst);
                     std::free(dst);
                     ++packed_layers;
