@@ -330,11 +330,14 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
         __syncthreads();
 
         // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
-        __builtin_amdgcn_sched_barrier(0);                 // keep the next chunk's loads (20 registers) behind the transform
+        // WN = 1 (32 -> 32 layers: 4 short chunks, 36 MFMAs each): the next chunk's loads go out BEFORE the transform - a
+        // chunk's MFMA phase alone (~2 us) is shorter than an HBM round trip under load
+        if constexpr (WN == 1) { if (c + 1 < nchunks) issue(c + 1); }
+        __builtin_amdgcn_sched_barrier(0);                 // WN = 2: keep the next chunk's loads (20 registers) behind the transform
         if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);
         else wino4_input_transform<1, PW, CKQ, PLANE>(patch + win, V + vout);
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunks) issue(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
+        if constexpr (WN == 2) { if (c + 1 < nchunks) issue(c + 1); }   // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();
 
         // ---- 9 GEMMs per wave: pair p = (k-step, k); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair -----
