@@ -86,7 +86,7 @@ def main(argv=None):
     from . import data as D
     from .drivers.greedy import GreedyEvaluator
     from .drivers.mcts import MCTS
-    from .drivers.sharded import run_sharded_greedy
+    from .drivers.sharded import run_sharded_greedy, run_sharded_mcts
     out = []
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dist = None
@@ -94,8 +94,8 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        if args.mode != "eval":
-            raise SystemExit("multi-GPU launch is implemented for `eval` (slices shard; one tree search needs one GPU)")
+        if args.mode == "flex":
+            raise SystemExit("multi-GPU launch is implemented for `eval` and `mcts` (slices / images shard over the ranks)")
     if args.mode == "eval":
         model, env, _ = _build(args, "norm")
         ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size,
@@ -116,19 +116,25 @@ def main(argv=None):
         return out
     if args.mode == "mcts":
         model, env, scorer = _build(args, "norm")
-        ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size)
-        for name, batch, tokens in _batches(args):
-            mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
-            n = mat["gt"].shape[0]
-            rtg = torch.full((n,), D.normalised_rtg(args.rtg))
-            # all images of the set are searched at once: one tree per image, children and rollouts batched over images;
-            # the policy's first token is the UNclipped Re x0 (datasets.py:162)
+        ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size,
+                             device_type=torch.device("cuda", torch.cuda.current_device()), sync_every=4)
+        for name, total, load in _sets(args):
+            def load_shard(a, b, load=load):
+                batch, tokens = load(a, b)
+                mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
+                return mat, torch.full((b - a,), D.normalised_rtg(args.rtg)), torch.from_numpy(tokens)
+            # all images of a rank's shard are searched at once: one tree per image, children and rollouts batched over images;
+            # the policy's first token is the UNclipped Re x0 (datasets.py:162; `x0_raw` of the batch)
             tree = MCTS(ev, scorer, rounds=args.rollouts, seed=args.seed)
-            psnr, _ = tree.run_batch(mat, rtg, torch.from_numpy(tokens), first_state=mat.get("x0_raw"))
-            out.append({"set": name, "n": n, "mcts_psnr": float(psnr.mean()),
-                        "rollouts_per_s": round(tree.last_stats["rollouts_per_s"], 2)})
-            print(json.dumps(out[-1]), flush=True)
-    else:
+            psnr, rollouts, secs = run_sharded_mcts(tree, total, load_shard)
+            out.append({"set": name, "n": total, "mcts_psnr": float(psnr.mean()),
+                        "rollouts_per_s": round(rollouts / secs, 2) if secs > 0 else 0.0, "ranks": world})
+            if rank == 0:
+                print(json.dumps(out[-1]), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return out
+    if True:
         model, env, _ = _build(args, "flex")
         ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size)
         for target in (1.5, 3, 3.5, 4, 4.5):                       # main.py:198

@@ -70,3 +70,29 @@ def run_sharded_greedy(evaluator: GreedyEvaluator, total: int,
     stop = sharding.gather_per_slice(local[2], total, group)
     return ShardedResult(reward=reward.cpu(), initial_reward=initial.cpu(), stop_time=stop.cpu(), local_range=(a, b),
                          seconds=float(dt.item()), steps=int(stop.max()) if total else 0)
+
+
+def run_sharded_mcts(tree, total: int, load_shard: Callable[[int, int], Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor]],
+                     group=None):
+    """BASELINE configs[3] over several GPUs: the images of a set are cut into contiguous shards like the slices of the greedy
+    episode, every rank searches its own images at once (`MCTS.run_batch`: one tree per image) and the per-image PSNR of the
+    best program is gathered - again the only exchange.  Returns (psnr [total, 1] CPU, rollouts of the whole job, seconds)."""
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    a, b = sharding.shard_range(total, rank, world)
+    dev = tree.ev.device
+    t0 = time.perf_counter()
+    if b > a:
+        mat, rtg, task = load_shard(a, b)
+        psnr, _ = tree.run_batch(mat, rtg, task)
+        local = psnr.to(dev).float()
+        rollouts = float(tree.last_stats["rollouts"])
+    else:
+        local, rollouts = torch.zeros((0, 1), device=dev), 0.0
+    stat = torch.tensor([time.perf_counter() - t0, rollouts], dtype=torch.float64, device=dev)
+    if world > 1:
+        secs = stat[:1].clone()
+        dist.all_reduce(secs, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+        stat[0] = secs[0]
+    return sharding.gather_per_slice(local, total, group).cpu(), float(stat[1]), float(stat[0])
