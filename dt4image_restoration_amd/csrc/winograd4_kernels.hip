@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     const int hh = lane >> 5, li = lane & 31;
 
     // XCD-aware decode: the channel groups of one spatial tile run back to back on the same XCD (blocks b and b + 8 share
-    // an XCD under round-robin placement - speed only), so the patch they all read is fetched into that L2 once.
+    // an XCD under round-robin placement - speed only), so the patch they all read is fetched into that L2 once.  (The
+    // opposite affinity - one channel block per XCD, so that its share of the transformed weights, 9.4 MB per 256 -> 256
+    // layer in all, stays L2-resident - measured 4-6 % SLOWER on every layer: the weights stream well from the Infinity Cache.)
     const int ny = a.Cout / (32 * WN);
     const int bid = blockIdx.x;
     const int grp = bid / (8 * ny), rem = bid % (8 * ny);
