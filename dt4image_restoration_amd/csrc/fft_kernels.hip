@@ -191,6 +191,80 @@ __device__ __forceinline__ void fft_lines_inplace(float2* buf, const float2* tw)
     }
 }
 
+// ---- 256-point lines as TWO radix-16 passes with the 16-point transforms in registers (2 LDS round trips per transform
+// instead of the 4 of the radix-4 passes) ------------------------------------------------------------------------------------
+// In place in one buffer; element i of a line lives at i + (i >> 4) (one pad element per 16: the Stockham passes read
+// positions j + 16 m and write 16 j + q / j + 16 q, which the skew turns into j + 17 m, 17 j + q, j + 17 q - lanes j hit
+// distinct banks in all three), lines SK256_LS elements apart.
+static constexpr int SK256_LS = 273;
+__device__ __forceinline__ int sk256(int i) { return i + (i >> 4); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4_inplace(float2& a, float2& b, float2& c, float2& d) {
+    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), e = csub(b, d);
+    const float2 t3 = INV ? make_float2(-e.y, e.x) : make_float2(e.y, -e.x);        // (+/- i) * (b - d)
+    a = cadd(t0, t2); b = cadd(t1, t3); c = csub(t0, t2); d = csub(t1, t3);
+}
+
+// v[0..15] -> its 16-point DFT, result X[p + 4 s] in v[4 p + s] (two radix-4 stages, constant twiddles w16^(r p) between)
+template <bool INV>
+__device__ __forceinline__ void dft16_inplace(float2* v) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4_inplace<INV>(v[r], v[r + 4], v[r + 8], v[r + 12]);   // A[r][p] now in v[r + 4 p]
+    // w16^e = (cos, -sin)(2 pi e / 16) forward, conjugate inverse; e = r * p
+    auto tw = [&](float2& x, float c, float sn) { x = cmul(x, make_float2(c, INV ? sn : -sn)); };
+    tw(v[1 + 4], C1, S1);   tw(v[2 + 4], R2, R2);   tw(v[3 + 4], S1, C1);           // p = 1: e = 1, 2, 3
+    tw(v[1 + 8], R2, R2);   tw(v[2 + 8], 0.f, 1.f); tw(v[3 + 8], -R2, R2);          // p = 2: e = 2, 4, 6
+    tw(v[1 + 12], S1, C1);  tw(v[2 + 12], -R2, R2); tw(v[3 + 12], -C1, -S1);        // p = 3: e = 3, 6, 9
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dft4_inplace<INV>(v[4 * p], v[4 * p + 1], v[4 * p + 2], v[4 * p + 3]);
+}
+
+// LINES (<= 16) lines of 256 points, 256 threads: thread (line, j) owns one radix-16 butterfly per pass.
+template <bool INV, int LINES>
+__device__ __forceinline__ void fft256_radix16_inplace(float2* buf, const float2* __restrict__ tw) {
+    const int tid = threadIdx.x, line = tid >> 4, j = tid & 15;
+    const bool on = line < LINES;
+    float2* const base = buf + line * SK256_LS;
+    float2 v[16];
+    // pass 1 (Ns = 1): no twiddles; X[q] -> position 16 j + q
+    if (on) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = base[j + 17 * m];
+    }
+    __syncthreads();                                       // in place: every read of the pass before any write
+    if (on) {
+        dft16_inplace<INV>(v);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) base[17 * j + p + 4 * s2] = v[4 * p + s2];
+    }
+    __syncthreads();
+    // pass 2 (Ns = 16, k = j): x[m] *= w256^(m j); X[q] -> position j + 16 q
+    if (on) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            v[m] = base[j + 17 * m];
+            if (m > 0) {
+                float2 w = tw[m * j];
+                if (INV) w.y = -w.y;
+                v[m] = cmul(v[m], w);
+            }
+        }
+    }
+    __syncthreads();
+    if (on) {
+        dft16_inplace<INV>(v);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) base[j + 17 * (p + 4 * s2)] = v[4 * p + s2];
+    }
+    __syncthreads();
+}
+
 static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in the row passes
 
 // MODE 0 generic (in -> out, index shifts), 1 ADMM forward (x + u -> work), 2 ADMM inverse (work -> z, u)
@@ -200,9 +274,13 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
                                                        const float2* __restrict__ twg, const float* __restrict__ tact,
                                                        int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    // (two radix-16 passes for 256-point rows measured 0.0506 against 0.0489 ms for the radix-4 passes: with 8 rows per
+    // workgroup only half the threads own a butterfly; the switch stays for experiments)
+    constexpr bool R16 = false && LC == 256;
+    auto slot = [&](int e) { return R16 ? (e >> 8) * SK256_LS + sk256(e & 255) : e; };
     float2* buf0 = smem;
-    float2* buf1 = smem + rpb * W;
-    float2* tw = smem + 2 * rpb * W;
+    float2* buf1 = smem + (R16 ? 0 : rpb * W);
+    float2* tw = smem + (R16 ? (ROW_ELEMS / 256) * SK256_LS : 2 * rpb * W);
     const int blocks_per_img = H / rpb;
     const int n = blockIdx.x / blocks_per_img;
     const int y0 = (blockIdx.x % blocks_per_img) * rpb;
@@ -228,13 +306,17 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int e = e0 + k * 256;
-            if (e < tot) buf0[e] = MODE == 1 ? make_float2(xv[k] + v[k].x, v[k].y) : v[k];
+            if (e < tot) buf0[slot(e)] = MODE == 1 ? make_float2(xv[k] + v[k].x, v[k].y) : v[k];
         }
     }
     __syncthreads();
     const bool inv = (MODE == 2) || (MODE == 0 && inverse);
     float2* res;
-    if constexpr (LC > 0) {                                // W == LC, rpb == ROW_ELEMS / LC (checked by the launcher)
+    if constexpr (R16) {                                   // W == 256, 8 rows per workgroup (checked by the launcher)
+        if (inv) fft256_radix16_inplace<true, ROW_ELEMS / 256>(buf0, tw);
+        else fft256_radix16_inplace<false, ROW_ELEMS / 256>(buf0, tw);
+        res = buf0;
+    } else if constexpr (LC > 0) {                         // W == LC, rpb == ROW_ELEMS / LC (checked by the launcher)
         if constexpr (MODE == 2) res = fft_lines_ct<true, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
         else if constexpr (MODE == 1) res = fft_lines_ct<false, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
         else res = inv ? fft_lines_ct<true, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw) : fft_lines_ct<false, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
@@ -256,7 +338,7 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
         for (int k = 0; k < NB; ++k) {
             const int e = e0 + k * 256;
             if (e < tot) {
-                float2 v = res[e];
+                float2 v = res[slot(e)];
                 v.x *= sc; v.y *= sc;
                 if (MODE == 2) {
                     out[base + e] = v;                                                   // z
@@ -279,7 +361,8 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
                                                        const float* __restrict__ tact, int H, int W, int cw,
                                                        int inverse, int shift_in, int shift_out) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int lstr = H + 1;
+    constexpr bool R16 = MODE == 1 && LC == 256;           // 256-point columns of the ADMM pass: radix-16 passes, skewed lines
+    const int lstr = R16 ? SK256_LS : H + 1;
     float2* buf0 = smem;
     float2* buf1 = smem + cw * lstr;
     float2* tw = smem + ((MODE == 1 && LC > 0) ? 1 : 2) * cw * lstr;   // the unrolled ADMM variant works in place in buf0
@@ -302,7 +385,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int e = e0 + k * 256;
-            if (e < tot) buf0[(e & (cw - 1)) * lstr + ((e >> lcw) ^ shift_in)] = v[k];
+            if (e < tot) buf0[(e & (cw - 1)) * lstr + (R16 ? sk256(e >> lcw) : ((e >> lcw) ^ shift_in))] = v[k];
         }
     }
     __syncthreads();
@@ -318,7 +401,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
     } else if constexpr (LC > 0) {
         // H == LC, cw == CWC (checked by the launcher): the k-space constants of this strip are fetched BEFORE the forward
         // transform and sit in registers under it; all passes unrolled.
-        constexpr int CWC = LC <= 256 ? 16 : (LC <= 512 ? 8 : 4), LS = LC + 1, PER = CWC * LC / 256;
+        constexpr int CWC = LC <= 256 ? 16 : (LC <= 512 ? 8 : 4), LS = R16 ? SK256_LS : LC + 1, PER = CWC * LC / 256;
         const float m = mu[n];
         const float inv1m = 1.f + m;
         const float2* y0n = y0s + (size_t)n * H * W;
@@ -332,27 +415,29 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
             mm[k] = mk[g];
             yy[k] = y0n[g];
         }
-        fft_lines_inplace<false, LC, CWC, LS>(buf0, tw);
+        if constexpr (R16) fft256_radix16_inplace<false, CWC>(buf0, tw);
+        else fft_lines_inplace<false, LC, CWC, LS>(buf0, tw);
         float2* const res = buf0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = threadIdx.x + k * 256;
             const int r = e / CWC, c = e % CWC;
-            float2 v = res[c * LS + r];
+            float2 v = res[c * LS + (R16 ? sk256(r) : r)];
             v.x *= sc; v.y *= sc;                           // now the orthonormal FFT2 of x + u
             if (mm[k]) {                                    // sampled k-space bin: closed-form solve
                 v.x = (m * v.x + yy[k].x) / inv1m;
                 v.y = (m * v.y + yy[k].y) / inv1m;
             }
-            res[c * LS + r] = v;
+            res[c * LS + (R16 ? sk256(r) : r)] = v;
         }
         __syncthreads();
-        fft_lines_inplace<true, LC, CWC, LS>(res, tw);
+        if constexpr (R16) fft256_radix16_inplace<true, CWC>(res, tw);
+        else fft_lines_inplace<true, LC, CWC, LS>(res, tw);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = threadIdx.x + k * 256;
             const int r = e / CWC, c = e % CWC;
-            float2 v = res[c * LS + r];
+            float2 v = res[c * LS + (R16 ? sk256(r) : r)];
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
         }
@@ -651,7 +736,7 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
     hipLaunchKernelGGL((fft_cols_kernel<1, LC_>), dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu, \
                        tact, H, W, cw, 0, 0, 0)
     const bool ct = cw == (H <= 256 ? 16 : (H <= 512 ? 8 : 4)) && (H == 128 || H == 256 || H == 512);   // W >= one full strip
-    if (ct) lds = (size_t)(cw * (H + 1) + H) * sizeof(float2);      // in place: one strip buffer
+    if (ct) lds = (size_t)(cw * (H == 256 ? SK256_LS : H + 1) + H) * sizeof(float2);      // in place: one strip buffer
     if (ct && H == 128) PNP_COLS_PROX(128);
     else if (ct && H == 256) PNP_COLS_PROX(256);
     else if (ct && H == 512) PNP_COLS_PROX(512);
