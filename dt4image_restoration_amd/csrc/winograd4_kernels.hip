@@ -27,6 +27,17 @@
 
 namespace pnp {
 
+// Diagnostic build only (make stamps -> libpnpadmm_stamps.so, read by tools/wino4_stamps.py): wave 0 of up to 1024 mid-grid
+// workgroups per launch accumulates s_memtime differences per phase.
+#ifdef PNP_STAMPS
+#define W4_SLOTS 32
+#define W4_WGS 1024
+#define W4_N 16
+__device__ unsigned long long g_w4_stamps[W4_SLOTS * W4_WGS * W4_N];
+static int g_w4_slot = 0;
+#define W4T() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 // points (0, +-a, +-b, inf), a = 3/4, b = 3/2
 constexpr double kA = 0.75, kB = 1.5;
@@ -172,6 +183,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][32 tiles][CKP]
     float* const lowres = V;                               // UPCAT: [LH][LW][CKP] low-res source region; V is dead while a
                                                            // chunk is staged (between the loop-top barrier and the transform)
+#ifdef PNP_STAMPS
+    unsigned long long st_t0 = W4T(), st_setup = 0, st_loop0 = 0, st_commit = 0, st_trans = 0, st_mfma = 0, st_loop1 = 0, st_ew = 0, st_er = 0, st_tmp = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wid / WN, cg = wid % WN;                 // frequency quadrant, 32-channel group of this wave
@@ -326,10 +340,20 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
     const int aoff = ((3 * qi) * 6 + 3 * qj) * PLANE + li * CKP + 4 * hh;          // this lane's row of V[(3qi, 3qj)]
 
+#ifdef PNP_STAMPS
+    st_setup = W4T();
+    st_loop0 = st_setup;
+#endif
     for (int c = 0; c < nchunks; ++c) {
+#ifdef PNP_STAMPS
+        st_tmp = W4T();
+#endif
         if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
         commit(c);
         __syncthreads();
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_commit += t - st_tmp; st_tmp = t; }
+#endif
 
         // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
         // WN = 1 (32 -> 32 layers: 4 short chunks, 36 MFMAs each): the next chunk's loads go out BEFORE the transform - a
@@ -341,6 +365,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (WN == 2) { if (c + 1 < nchunks) issue(c + 1); }   // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_trans += t - st_tmp; st_tmp = t; }
+#endif
 
         // ---- 9 GEMMs per wave: pair p = (k-step, k); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair -----
         const float4* bp = bptr + (size_t)c * PAIRS * 64;
@@ -362,7 +389,13 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
             if (p + 1 < PAIRS) a0 = a1;
         }
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_mfma += t - st_tmp; }
+#endif
     }
+#ifdef PNP_STAMPS
+    st_loop1 = W4T();
+#endif
 
     // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1].
     // Wave (qi, qj) holds M[3qi..3qi+2][3qj..3qj+2] and forms its partial tile  Yp = A^T[:, 3qi..] M_q A[3qj.., :]  (lane-local).
@@ -386,8 +419,11 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             t[0] = s; t[1] = fB * d; t[2] = fB2 * s; t[3] = fmaf(fB3, d, m2);
         }
     };
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < 4; ++g) {
+#ifdef PNP_STAMPS
+        st_tmp = W4T();
+#endif
         __syncthreads();                                   // V (first round) / the previous round's partials are no longer read
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -395,13 +431,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
 #pragma unroll
             for (int kj = 0; kj < 3; ++kj) {
                 float m0, m1, m2;
-                // accumulator register 4g + rr with a compile-time index per round
-                switch (g) {
-                    case 0: m0 = acc[0 + kj][0 + rr]; m1 = acc[3 + kj][0 + rr]; m2 = acc[6 + kj][0 + rr]; break;
-                    case 1: m0 = acc[0 + kj][4 + rr]; m1 = acc[3 + kj][4 + rr]; m2 = acc[6 + kj][4 + rr]; break;
-                    case 2: m0 = acc[0 + kj][8 + rr]; m1 = acc[3 + kj][8 + rr]; m2 = acc[6 + kj][8 + rr]; break;
-                    default: m0 = acc[0 + kj][12 + rr]; m1 = acc[3 + kj][12 + rr]; m2 = acc[6 + kj][12 + rr]; break;
-                }
+                m0 = acc[0 + kj][4 * g + rr]; m1 = acc[3 + kj][4 * g + rr]; m2 = acc[6 + kj][4 * g + rr];
                 at4(qi, m0, m1, m2, t[kj]);
             }
             float* pw = P + ((((cg * 4 + q) * 4 + rr) * 16) * 64) + lane;
@@ -414,6 +444,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             }
         }
         __syncthreads();
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_ew += t - st_tmp; st_tmp = t; }
+#endif
         // reduce + finish: tile t = rr + 8g + 4hh of the M-block, window (wy, wx) of its 4x4 pixels
         {
             const int t = r_rr + 8 * g + 4 * r_hh;
@@ -458,8 +491,22 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
                         f4max(f4max(o[0], o[1]), f4max(o[2], o[3]));
             }
         }
+#ifdef PNP_STAMPS
+        st_er += W4T() - st_tmp;
+#endif
     }
     (void)V4;
+#ifdef PNP_STAMPS
+    {
+        const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
+        if (tid == 0 && w >= 0 && w < W4_WGS && a.stamp_slot < W4_SLOTS) {
+            unsigned long long* o = g_w4_stamps + ((size_t)a.stamp_slot * W4_WGS + w) * W4_N;
+            const unsigned long long te = W4T();
+            o[0] = 1; o[1] = st_setup - st_t0; o[2] = st_commit; o[3] = st_trans; o[4] = st_mfma; o[5] = st_loop1 - st_loop0;
+            o[6] = st_ew; o[7] = st_er; o[8] = te - st_loop1; o[9] = te - st_t0; o[10] = (unsigned long long)nchunks;
+        }
+    }
+#endif
 }
 
 template <int TW, int SRC, bool STK = false, int WN = 2>
@@ -485,6 +532,9 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
+#ifdef PNP_STAMPS
+    a.stamp_slot = g_w4_slot++;
+#endif
     if (p.bn == 32) {                                      // Cout = 32: 4-wave workgroups, 8-channel chunks, two per CU
         if (p.ck != 8 || p.stack) return hipErrorInvalidValue;
         if (p.tw == 32 && src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN, false, 1>(a, p, s);
@@ -506,3 +556,10 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
 }
 
 }  // namespace pnp
+
+#ifdef PNP_STAMPS
+extern "C" int pnp_debug_stamps4_reset(void) { pnp::g_w4_slot = 0; return 0; }
+extern "C" int pnp_debug_stamps4_read(unsigned long long* dst, int slots) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pnp::g_w4_stamps), (size_t)slots * W4_WGS * W4_N * sizeof(unsigned long long));
+}
+#endif
