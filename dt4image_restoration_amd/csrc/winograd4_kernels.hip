@@ -10,20 +10,23 @@
 // (3x the F(2x2) kernel's, 6x the direct sum's; tools/wino_points.py scans the candidates).  All arithmetic is f32; the
 // weight transform G g G^T is done once on the host in f64.
 //
-// Workgroup = 8 waves = 4 frequency quadrants (3x3 blocks of the 6x6 frequency grid) x 2 groups of 32 output channels,
-// working on 32 tiles (512 output pixels) x 64 channels; every wave holds 9 accumulators of 32 tiles x 32 channels
-// (144 registers), two waves per SIMD.  Per 16-channel chunk:
+// Workgroup = 8 waves on 32 tiles (512 output pixels) x 64 output channels; wave (th, cq) OWNS 16 tiles x 16 channels for
+// ALL 36 frequencies: 36 accumulators of v_mfma_f32_16x16x4_f32 (144 registers), two waves per SIMD.  Per 16-channel chunk:
 //   1. stage the (TH+2) x (TW+2) halo patch in LDS (loads of chunk c+1 in flight during chunk c's MFMAs; upsampled chunks
 //      come from the tile's low-res source region parked in LDS, like the F(2x2) kernel)
 //   2. input transform: thread (tile, 2 channels, frequency-column group) reads the 6x5 part of the 6x6 window its three
 //      frequency columns need and writes their 18 frequency planes V[xi][tile][channel] (no value is computed twice)
-//   3. 36 independent GEMMs, 9 per wave: acc[xi] += V[xi] (A fragment, ds_read_b128) x U[xi] (B fragment, transformed
-//      weights streamed from L2 in pre-packed per-lane order)
-// Output transform: every wave turns its 3x3 block of M into a PARTIAL 4x4 output tile (lane-local), the four partials
-// meet in LDS and are summed in a fixed order (bit-reproducible) by threads that own (2x2 pixel window, 4 channels):
-// + bias, LeakyReLU, 16-byte NHWC stores and the 2x2 max-pooled copy for the next stage from the same registers.
+//   3. 36 independent GEMMs per wave: acc[xi] += V[xi] (A fragment, one ds_read_b128 per frequency, swizzled so that the
+//      16-lane read groups are conflict-free without padding) x U[xi] (B fragment, transformed weights streamed from L2 in
+//      pre-packed per-lane order)
+// Output transform Y = A^T M A is LANE-LOCAL: a lane holds all 36 frequencies of its 4 tiles x 1 channel, so there is no
+// exchange through LDS and no barrier after the MFMA loop (the previous generation split the frequencies over four waves and
+// met in LDS: 256 ds_write_b32 per lane, ~15k cycles per workgroup - 40 % of a 32 -> 32 layer's lifetime,
+// profiles/r02_wino4_stamps.md).  + bias, LeakyReLU, NHWC stores (16 consecutive channels = 64 bytes per pixel and wave, the
+// neighbouring wave writes the other half of the line) and the 2x2 max-pooled copy for the next stage from the same registers.
 #include "pnp_internal.h"
 #include "conv_staging.h"
+#include <type_traits>
 
 namespace pnp {
 
@@ -49,6 +52,7 @@ constexpr float fA2B = 0.84375f;      // a^2 b
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One-dimensional input transform, three of the six outputs.  B^T rows (ascending powers of the window index):
 //   0: [a^2 b^2, 0, -(a^2+b^2), 0, 1, 0]   1,2: [0, -+a b^2, -b^2, +-a, 1, 0]
@@ -104,11 +108,14 @@ __device__ __forceinline__ void wino4_input_transform(const float* w, float* v) 
 }
 }  // namespace
 
-// ---- host: U = G g G^T (6x6 per (cout, cin)), packed [cout/32][quadrant 4][chunk][ks 2][k 9][lane 64][4] -----------------
-size_t winograd4_pack_floats(int cin, int cout) { return (size_t)(cout / 32) * ((size_t)(cin / 8) * 36 * 256 + 4 * 4 * 256); }
+// ---- host: U = G g G^T (6x6 per (cout, cin)), packed [cout/16][chunk][xi 36][lane 64][CK/4] (+ a prefetch tail per stream) ---
+// Lane l of a v_mfma_f32_16x16x4_f32 B operand holds U[xi][cin = CK*chunk + (CK/4)*(l/16) + s][cout = 16*cb + l%16] for the
+// MFMA number s = 0..CK/4-1 of the frequency.
+constexpr int kW4Tail = 8 * 64 * 4;                     // floats: the B ring reads up to 6 fragments past the last chunk
+size_t winograd4_pack_floats(int cin, int cout) { return (size_t)cout * cin * 36 + (size_t)(cout / 16) * kW4Tail; }
 
 void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float* dst) {
-    const int CK = ck;                                  // 16 (64-channel workgroups) or 8 (32-channel workgroups)
+    const int CK = ck, S = CK / 4;                      // 16 (64-channel workgroups) or 8 (32-channel workgroups)
     // G rows: p^k / N_p for the finite points, [0 0 1] for infinity; N_p = prod_{q != p} (p - q)
     const double pts[5] = {0.0, kA, -kA, kB, -kB};
     double G[6][3];
@@ -130,32 +137,28 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
                     U[((size_t)co * cin + ci) * 36 + 6 * i + j] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
         }
     size_t o = 0;
-    for (int cb = 0; cb < cout / 32; ++cb)
-        for (int q = 0; q < 4; ++q) {                       // quadrant (qi, qj): frequency rows 3qi..3qi+2, columns 3qj..3qj+2
-            const int qi = q >> 1, qj = q & 1;
-            for (int ch = 0; ch < cin / CK; ++ch)
-                for (int ks = 0; ks < CK / 8; ++ks)
-                    for (int k = 0; k < 9; ++k)
-                        for (int l = 0; l < 64; ++l)
-                            for (int j = 0; j < 4; ++j) {
-                                const int co = 32 * cb + (l & 31);
-                                const int ci = CK * ch + 8 * ks + 4 * (l >> 5) + j;
-                                const int xi = (3 * qi + k / 3) * 6 + 3 * qj + k % 3;
-                                dst[o++] = U[((size_t)co * cin + ci) * 36 + xi];
-                            }
-            for (int i = 0; i < 4 * 256; ++i) dst[o++] = 0.f;   // prefetch tail of this stream
-        }
+    for (int cb = 0; cb < cout / 16; ++cb) {
+        for (int ch = 0; ch < cin / CK; ++ch)
+            for (int xi = 0; xi < 36; ++xi)
+                for (int l = 0; l < 64; ++l)
+                    for (int sidx = 0; sidx < S; ++sidx) {
+                        const int co = 16 * cb + (l & 15);
+                        const int ci = CK * ch + S * (l >> 4) + sidx;
+                        dst[o++] = U[((size_t)co * cin + ci) * 36 + xi];
+                    }
+        for (int i = 0; i < kW4Tail; ++i) dst[o++] = 0.f;       // prefetch tail of this stream
+    }
 }
 
 // STK (TW = 16, SRC_PLAIN, 16 x 16 images only - the bottom level of a 256 x 256 slice): the workgroup's 32 tiles are the
 // 4 x 4 tiles of TWO consecutive slices stacked (tile rows 0..3 -> slice n0, 4..7 -> slice n0 + 1; two 18-row halo patches
 // one above the other), so the 32-tile M-block is full instead of half padding.
 // WN = 2: 8 waves, 64 output channels, 16-channel chunks, one workgroup per CU (the layout described above).
-// WN = 1 (Cout = 32, the full-resolution layers): 4 waves = the 4 quadrants of ONE 32-channel group, 8-channel chunks, and the
-// LDS cut to 79.8 KB (patch pixel stride 10 floats instead of 12) so that TWO workgroups share a CU.
+// WN = 1 (Cout = 32, the full-resolution layers): 4 waves = 2 tile halves x 2 groups of 16 channels, 8-channel chunks (two
+// MFMAs per frequency, b64 fragments), 61 KB of LDS so that TWO workgroups share a CU.
 template <int TW, int SRC, bool STK = false, int WN = 2>
 __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
-    constexpr int CK = 8 * WN, CKP = CK + 4, PPP = CK / 4, NT_ = 256 * WN;
+    constexpr int CK = 8 * WN, CKP = CK, LP = CK + 4, PPP = CK / 4, NT_ = 256 * WN;   // CKP / LP: pixel stride of V / the low-res region
     constexpr int CKQ = WN == 2 ? CK + 4 : CK + 2;     // patch pixel stride (floats): b64 window reads conflict-free for both
     constexpr int HCN = CK / 2;                        // 2-channel units per pixel
     constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
@@ -170,27 +173,26 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     constexpr int LITEMS = LH * LW * PPP;
     constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
     constexpr int NRAW = (UP2 && NITL > NIT) ? NITL : NIT;
-    constexpr int KSC = CK / 8;                        // k-steps per chunk
-    constexpr int PAIRS = 9 * KSC;                     // (k-step, frequency) pairs per chunk and wave, 4 MFMAs each
-    constexpr int PF = 3;                              // B fragments in flight (must divide PAIRS: slots line up across chunks)
+    constexpr int S = CK / 4;                          // MFMAs (4 channels each) per frequency and chunk
+    constexpr int PF = WN == 2 ? 9 : 12;               // B fragments in flight in the MFMA loop (must divide 36: slots line up
+                                                       // across chunks) ...
+    constexpr int KEEP = 3;                            // ... of which only the first KEEP are loaded across the chunk boundary (the
+                                                       // input transform needs the registers); the rest go out after the transform
     constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
     static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
-    static_assert(PAIRS % PF == 0 && 32 * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
-    static_assert(LH * LW * CKP <= 36 * PLANE, "the low-res region is parked in V's space");
+    static_assert(36 % PF == 0 && 32 * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKQ]
     float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][32 tiles][CKP]
-    float* const lowres = V;                               // UPCAT: [LH][LW][CKP] low-res source region; V is dead while a
-                                                           // chunk is staged (between the loop-top barrier and the transform)
+    float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][LP] low-res source region of the chunk being staged
 #ifdef PNP_STAMPS
     unsigned long long st_t0 = W4T(), st_setup = 0, st_loop0 = 0, st_commit = 0, st_trans = 0, st_mfma = 0, st_loop1 = 0, st_ew = 0, st_er = 0, st_tmp = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = wid / WN, cg = wid % WN;                 // frequency quadrant, 32-channel group of this wave
-    const int qi = q >> 1, qj = q & 1;
-    const int hh = lane >> 5, li = lane & 31;
+    const int cq = wid >> 1, th = wid & 1;                 // this wave's 16-channel group and half of the 32 tiles
+    const int tg = lane >> 4, cl = lane & 15;              // MFMA lane = (k / row group tg, column / row cl)
 
     // XCD-aware decode: the channel groups of one spatial tile run back to back on the same XCD (blocks b and b + 8 share
     // an XCD under round-robin placement - speed only), so the patch they all read is fetched into that L2 once.  (The
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     const bool live0 = !(a.tact != nullptr && a.tact[n] > 0.5f);
     const bool live1 = STK && nsl == 2 && !(a.tact != nullptr && a.tact[n + 1] > 0.5f);
     if (!live0 && !live1) return;
-    const int cb = cby * WN + cg;                          // this wave's 32-channel block
+    const int cb = cby * (2 * WN) + cq;                    // this wave's 16-channel block
     const int nchunks = a.Cin / CK;
 
     const int Hs = a.H >> 1, Ws = a.W >> 1;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
         }
     }
     const int ldst = ((tid / PPP) * CKQ + (tid % PPP) * 4);      // patch slot of item 0; item k is k * (NT_ / PPP) pixels further
-    const int ldstL = ((tid / PPP) * CKP + (tid % PPP) * 4);     // the same in the low-res region (pixel stride CKP)
+    const int ldstL = ((tid / PPP) * LP + (tid % PPP) * 4);      // the same in the low-res region (pixel stride LP)
     auto put_patch = [&](int off, float4 v) {              // pixel stride 10 floats (WN = 1) is only 8-byte aligned
         if constexpr (CKQ % 4 == 0) *reinterpret_cast<float4*>(&patch[off]) = v;
         else { *reinterpret_cast<float2*>(&patch[off]) = make_float2(v.x, v.y); *reinterpret_cast<float2*>(&patch[off + 2]) = make_float2(v.z, v.w); }
@@ -274,37 +276,15 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
         for (int k = 0; k < NIT; ++k)
             raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
     };
-    auto commit = [&](int c) {
+    // registers -> LDS: the patch itself (plain chunks) or the low-res source region (upsampled chunks).  Runs right after a
+    // wave's MFMA phase of the previous chunk - the patch and the low-res region are dead from the post-transform barrier on -
+    // so it overlaps the partner waves' MFMAs and needs no barrier of its own.
+    auto park = [&](int c) {
         if (UP2 && c >= nskip) {
-            // park the low-res region in LDS, then interpolate the patch from it (ATen upsample_bilinear2d,
-            // align_corners=True: src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
 #pragma unroll
             for (int k = 0; k < NITL; ++k) {
                 const int idx = tid + k * NT_;
-                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[ldstL + k * (NT_ / PPP) * CKP]) = raw[k];
-            }
-            __syncthreads();
-#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
-            for (int k = 0; k < NIT; ++k) {
-                const int idx = tid + k * NT_;
-                const int part = idx % PPP, pp = idx / PPP;
-                const int py = pp / PW, px = pp % PW;
-                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-                if (idx < ITEMS) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                        const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
-                        const int y0 = (int)sy, x0 = (int)sx;
-                        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-                        const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
-                        const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * CKP + part * 4];
-                        const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * CKP + part * 4];
-                        v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * CKP), *reinterpret_cast<const float4*>(r0 + x1 * CKP),
-                                    *reinterpret_cast<const float4*>(r1 + x0 * CKP), *reinterpret_cast<const float4*>(r1 + x1 * CKP),
-                                    1.f - lx, lx, 1.f - ly, ly);
-                    }
-                    put_patch((py * PW + px) * CKQ + part * 4, v);
-                }
+                if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[ldstL + k * (NT_ / PPP) * LP]) = raw[k];
             }
             return;
         }
@@ -314,31 +294,63 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             if (idx < ITEMS) put_patch(ldst + k * (NT_ / PPP) * CKQ, raw[k]);
         }
     };
+    // upsampled chunk: interpolate the patch from the parked low-res region (ATen upsample_bilinear2d, align_corners=True:
+    // src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
+    auto interpolate = [&]() {
+#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * NT_;
+            const int part = idx % PPP, pp = idx / PPP;
+            const int py = pp / PW, px = pp % PW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            if (idx < ITEMS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
+                    const int y0 = (int)sy, x0 = (int)sx;
+                    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+                    const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * LP + part * 4];
+                    const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * LP + part * 4];
+                    v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * LP), *reinterpret_cast<const float4*>(r0 + x1 * LP),
+                                *reinterpret_cast<const float4*>(r1 + x0 * LP), *reinterpret_cast<const float4*>(r1 + x1 * LP),
+                                1.f - lx, lx, 1.f - ly, ly);
+                }
+                put_patch((py * PW + px) * CKQ + part * 4, v);
+            }
+        }
+    };
     issue(0);
+    park(0);
 
     // this thread's transform item: tile tq of the workgroup's 32 tiles (TC per row), channels [2*hc, 2*hc+2), frequency
     // column group tj (first half of the waves: columns 0..2, second half: columns 3..5; all six rows).  HCN lanes cover a
     // tile's channels and a 32-lane ds_read_b64 group covers 4 tiles 80 floats apart (WN = 2) or 8 tiles 40 floats apart
     // (WN = 1): all 64 banks, conflict-free.
+    // V has NO padding (pixel stride CK floats); the channel granules of a tile are permuted instead (swz) so that the MFMA
+    // phase's A reads are conflict-free: WN = 2, ds_read_b128 in 16-lane groups {tiles 0-3, 12-15 | granule g} + {tiles 4-11 |
+    // granule g+1}: granule position = g ^ m[tile / 4], m = {0, 3, 2, 1};  WN = 1, ds_read_b64 in 32-lane groups {16 tiles x
+    // 2 granules}: position = g ^ 2 * (tile / 8).
+    auto swz = [](int t16, int g) { return WN == 2 ? (g ^ ((4 - (t16 >> 2)) & 3)) : (g ^ ((t16 >> 3) << 1)); };
     const int hc = tid % HCN, tq = (tid / HCN) & 31;
     const int tj = wid / (2 * WN);
     const int trow = tq / TC;                                                  // tile row; stacked: rows 0..3 / 4..7 = slice 0 / 1
     const int wrow = STK ? (trow / (TR / 2)) * SUBH + 4 * (trow % (TR / 2)) : 4 * trow;
     const int win = (wrow * PW + 4 * (tq % TC)) * CKQ + 2 * hc;                // top-left of tile tq's 6x6 input window
-    const int vout = tq * CKP + 2 * hc;                                        // this item's slot in every frequency plane
+    const int vout = WN == 2 ? tq * CKP + 4 * swz(tq & 15, hc >> 1) + 2 * (hc & 1)      // this item's slot in every frequency plane
+                             : tq * CKP + 2 * swz(tq & 15, hc);
 
-    f32x16 acc[9];
+    f32x4 acc[36];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const size_t stream = (size_t)nchunks * PAIRS * 64 + 4 * 64;                   // float4 per (cb, quadrant) stream
-    const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + ((size_t)cb * 4 + q) * stream + lane;
-    float4 bq[PF];
+    typedef typename std::conditional<WN == 2, float4, float2>::type frag_t;      // S channels of one lane's A / B fragment
+    const size_t stream = (size_t)nchunks * 36 * 64 + kW4Tail / S;                // fragments per 16-channel block's stream
+    const frag_t* bptr = reinterpret_cast<const frag_t*>(a.wpack) + (size_t)cb * stream + lane;
+    frag_t bq[PF];
 #pragma unroll
-    for (int p = 0; p < PF; ++p) bq[p] = bptr[p * 64];
-    const int aoff = ((3 * qi) * 6 + 3 * qj) * PLANE + li * CKP + 4 * hh;          // this lane's row of V[(3qi, 3qj)]
+    for (int p = 0; p < KEEP; ++p) bq[p] = bptr[p * 64];
+    const int aoff = (16 * th + cl) * CKP + S * swz(cl, tg);                      // this lane's fragment of V[0]
 
 #ifdef PNP_STAMPS
     st_setup = W4T();
@@ -348,154 +360,135 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
 #ifdef PNP_STAMPS
         st_tmp = W4T();
 #endif
-        if (c > 0) __syncthreads();                        // MFMA phase of the previous chunk is done with V
-        commit(c);
-        __syncthreads();
+        __syncthreads();                                   // chunk c is parked; the previous chunk's MFMA phase is done with V
+        if (UP2 && c >= nskip) { interpolate(); __syncthreads(); }
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_commit += t - st_tmp; st_tmp = t; }
 #endif
 
         // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
-        // WN = 1 (32 -> 32 layers: 4 short chunks, 36 MFMAs each): the next chunk's loads go out BEFORE the transform - a
-        // chunk's MFMA phase alone (~2 us) is shorter than an HBM round trip under load
+        // WN = 1 (32 -> 32 layers: 4 short chunks): the next chunk's loads go out BEFORE the transform - a chunk's MFMA phase
+        // alone (~2 us) is shorter than an HBM round trip under load
         if constexpr (WN == 1) { if (c + 1 < nchunks) issue(c + 1); }
         __builtin_amdgcn_sched_barrier(0);                 // WN = 2: keep the next chunk's loads (20 registers) behind the transform
         if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);
         else wino4_input_transform<1, PW, CKQ, PLANE>(patch + win, V + vout);
         __builtin_amdgcn_sched_barrier(0);
+        const frag_t* bp = bptr + (size_t)c * 36 * 64;
+#pragma unroll
+        for (int p = KEEP; p < PF; ++p) bq[p] = bp[p * 64];
         if constexpr (WN == 2) { if (c + 1 < nchunks) issue(c + 1); }   // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_trans += t - st_tmp; st_tmp = t; }
 #endif
 
-        // ---- 9 GEMMs per wave: pair p = (k-step, k); A from V (LDS), B from the packed U stream (L2), 4 MFMAs per pair -----
-        const float4* bp = bptr + (size_t)c * PAIRS * 64;
-        float4 a0 = *reinterpret_cast<const float4*>(&V[aoff]);
+        // ---- 36 GEMMs per wave: A from V (LDS), B from the packed U stream (L2), S MFMAs per frequency ----------------------
+        frag_t ar[3];                                      // A fragments two frequencies ahead (LDS latency > one group of MFMAs)
+        ar[0] = *reinterpret_cast<const frag_t*>(&V[aoff]);
+        ar[1] = *reinterpret_cast<const frag_t*>(&V[PLANE + aoff]);
 #pragma unroll
-        for (int p = 0; p < PAIRS; ++p) {
-            float4 a1;
-            if (p + 1 < PAIRS) {
-                const int ks1 = (p + 1) / 9, k1 = (p + 1) % 9;
-                a1 = *reinterpret_cast<const float4*>(&V[((k1 / 3) * 6 + k1 % 3) * PLANE + aoff + 8 * ks1]);
+        for (int xi = 0; xi < 36; ++xi) {
+            if (xi + 2 < 36) ar[(xi + 2) % 3] = *reinterpret_cast<const frag_t*>(&V[(xi + 2) * PLANE + aoff]);
+            __builtin_amdgcn_sched_barrier(0);
+            const frag_t a0 = ar[xi % 3], b0 = bq[xi % PF];
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[xi], 0, 0, 0);
+            if constexpr (WN == 2) {
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[xi], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int k = p % 9;
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq[p % PF].x, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq[p % PF].y, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq[p % PF].z, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq[p % PF].w, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            bq[p % PF] = bp[(p + PF) * 64];                // refill the slot just read (tail zero-padded)
-            if (p + 1 < PAIRS) a0 = a1;
+            // refill the slot just read: this chunk's fragment xi + PF, or one of the next chunk's first KEEP (the stream is
+            // contiguous across chunks; tail zero-padded)
+            if (xi + PF < 36 + KEEP) bq[xi % PF] = bp[(xi + PF) * 64];
         }
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_mfma += t - st_tmp; }
 #endif
+        if (c + 1 < nchunks) park(c + 1);
     }
 #ifdef PNP_STAMPS
     st_loop1 = W4T();
+    st_tmp = st_loop1;
 #endif
 
-    // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1].
-    // Wave (qi, qj) holds M[3qi..3qi+2][3qj..3qj+2] and forms its partial tile  Yp = A^T[:, 3qi..] M_q A[3qj.., :]  (lane-local).
-    // Four rounds of 4 accumulator registers (8 tiles): partials -> P[cg][q][rr][16 outputs][64 lanes] in LDS, barrier, then
-    // thread (cg, rr, hh, 2x2 window, 4 channels) sums the four quadrants in the order q = 0..3 and finishes the pixels.
-    float* const P = smem;
-    constexpr int V4 = 8;                                   // float4 per 32-channel group
-    constexpr int CGB = WN == 2 ? 1 : 0;                   // bits of the channel-group field in the reducer's thread index
-    const int r_c4 = tid & 7, r_cg = (tid >> 3) & (WN - 1), r_hh = (tid >> (3 + CGB)) & 1, r_w = (tid >> (4 + CGB)) & 3,
-              r_rr = tid >> (6 + CGB);
-    const int cout0 = cby * (32 * WN) + r_cg * 32 + 4 * r_c4;
-    const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + cout0);
+    // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1],
+    // lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at
+    // a time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).
+    const int cout0 = cb * 16 + cl;
+    const float bias = a.bias[cout0];
     const int Hp = a.H >> 1, Wp = a.W >> 1;
-    // one-dimensional partial output transform of three values (the quadrant's rows or columns) into four
-    auto at4 = [&](int g, float m0, float m1, float m2, float* t) {
-        if (g == 0) {            // frequencies 0, a, -a
-            const float s = m1 + m2, d = m1 - m2;
-            t[0] = m0 + s; t[1] = fA * d; t[2] = fA2 * s; t[3] = fA3 * d;
-        } else {                 // frequencies b, -b, inf
-            const float s = m0 + m1, d = m0 - m1;
-            t[0] = s; t[1] = fB * d; t[2] = fB2 * s; t[3] = fmaf(fB3, d, m2);
-        }
+    const bool live = STK ? (th == 0 ? live0 : live1) : true;                       // stacked: wave th works on slice n + th
+    auto at6 = [&](v2f m0, v2f m1, v2f m2, v2f m3, v2f m4, v2f m5, v2f* t) {
+        const v2f s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        t[0] = m0 + s1 + s2;
+        t[1] = fA * d1 + fB * d2;
+        t[2] = fA2 * s1 + fB2 * s2;
+        t[3] = fA3 * d1 + fB3 * d2 + m5;
     };
+    if (live) {
+        const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.pooled != nullptr ? a.pooled + (size_t)(n + (STK ? th : 0)) * Hp * Wp * a.Cout : a.dst), 0,
+            a.pooled != nullptr ? Hp * Wp * a.Cout * 4 : 0, 0x00020000);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#ifdef PNP_STAMPS
-        st_tmp = W4T();
-#endif
-        __syncthreads();                                   // V (first round) / the previous round's partials are no longer read
+        for (int rp = 0; rp < 2; ++rp) {
+            v2f T[4][6];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            float t[3][4];                                 // [kj][a']: rows transformed, per frequency column of the quadrant
+            for (int j = 0; j < 6; ++j) {
+                v2f m[6];
 #pragma unroll
-            for (int kj = 0; kj < 3; ++kj) {
-                float m0, m1, m2;
-                m0 = acc[0 + kj][4 * g + rr]; m1 = acc[3 + kj][4 * g + rr]; m2 = acc[6 + kj][4 * g + rr];
-                at4(qi, m0, m1, m2, t[kj]);
+                for (int i = 0; i < 6; ++i) m[i] = v2f{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]};
+                v2f t[4];
+                at6(m[0], m[1], m[2], m[3], m[4], m[5], t);
+#pragma unroll
+                for (int ay = 0; ay < 4; ++ay) T[ay][j] = t[ay];
             }
-            float* pw = P + ((((cg * 4 + q) * 4 + rr) * 16) * 64) + lane;
+            v2f Y[4][4];
 #pragma unroll
             for (int ay = 0; ay < 4; ++ay) {
-                float y[4];
-                at4(qj, t[0][ay], t[1][ay], t[2][ay], y);
+                at6(T[ay][0], T[ay][1], T[ay][2], T[ay][3], T[ay][4], T[ay][5], Y[ay]);
 #pragma unroll
-                for (int bx = 0; bx < 4; ++bx) pw[(ay * 4 + bx) * 64] = y[bx];
-            }
-        }
-        __syncthreads();
-#ifdef PNP_STAMPS
-        { const unsigned long long t = W4T(); st_ew += t - st_tmp; st_tmp = t; }
-#endif
-        // reduce + finish: tile t = rr + 8g + 4hh of the M-block, window (wy, wx) of its 4x4 pixels
-        {
-            const int t = r_rr + 8 * g + 4 * r_hh;
-            const int tr = t / TC;
-            const int sub = STK ? tr / (TR / 2) : 0;                        // stacked: the slice this tile belongs to
-            const bool live = STK ? (sub == 0 ? live0 : live1) : true;
-            const int py = (STK ? 4 * (tr % (TR / 2)) : 4 * tr) + 2 * (r_w >> 1), px = 4 * (t % TC) + 2 * (r_w & 1);
-            const float* pr = P + (((r_cg * 4) * 4 + r_rr) * 16) * 64 + r_hh * 32 + 4 * r_c4;
-            float4 o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int oidx = (2 * (r_w >> 1) + (e >> 1)) * 4 + 2 * (r_w & 1) + (e & 1);
-                float4 s = *reinterpret_cast<const float4*>(pr + oidx * 64);
-#pragma unroll
-                for (int qq = 1; qq < 4; ++qq) s = f4add(s, *reinterpret_cast<const float4*>(pr + (qq * 4 * 16 + oidx) * 64));
-                s = f4add(s, bias4);
-                o[e] = make_float4(fmaxf(s.x, kLeaky * s.x), fmaxf(s.y, kLeaky * s.y), fmaxf(s.z, kLeaky * s.z), fmaxf(s.w, kLeaky * s.w));
-                const int gy = ty0 + py + (e >> 1), gx = tx0 + px + (e & 1);
-                if constexpr (WN == 1) {
-                    if (a.last_w != nullptr) {
-                        // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp.  The eight
-                        // threads c4 = 0..7 of a pixel hold its 32 channels: partial dot products, xor-shuffled together; this
-                        // conv's own 32-channel output is never written.
-                        const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * r_c4);
-                        float dsum = o[e].x * wv.x + o[e].y * wv.y + o[e].z * wv.z + o[e].w * wv.w;
-                        dsum += __shfl_xor(dsum, 1); dsum += __shfl_xor(dsum, 2); dsum += __shfl_xor(dsum, 4);
-                        if (r_c4 == 0 && gy < a.H && gx < a.W) {
-                            const size_t qx = ((size_t)n * a.H + gy) * a.W + gx;
-                            const float img = a.last_ximg != nullptr ? a.last_ximg[qx] : (a.last_z[qx].x - a.last_u[qx].x);
-                            a.last_out[qx] = fminf(fmaxf(img + dsum + a.last_b[0], 0.f), 1.f);
-                        }
-                        continue;
-                    }
+                for (int ax = 0; ax < 4; ++ax) {
+                    const v2f sv = Y[ay][ax] + bias;
+                    Y[ay][ax] = v2f{fmaxf(sv.x, kLeaky * sv.x), fmaxf(sv.y, kLeaky * sv.y)};
                 }
-                if (live && gy < a.H && gx < a.W)
-                    *reinterpret_cast<float4*>(a.dst + (((size_t)(n + sub) * a.H + gy) * a.W + gx) * a.Cout + cout0) = o[e];
             }
-            if (a.pooled != nullptr) {                     // MaxPool2d(2) of this window for the next stage (noise.py:22-25)
-                const int gy = (ty0 + py) >> 1, gx = (tx0 + px) >> 1;
-                if (live && gy < Hp && gx < Wp)
-                    *reinterpret_cast<float4*>(a.pooled + (((size_t)(n + sub) * Hp + gy) * Wp + gx) * a.Cout + cout0) =
-                        f4max(f4max(o[0], o[1]), f4max(o[2], o[3]));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int t = 16 * th + 4 * tg + 2 * rp + e;                       // tile of the M-block
+                const int tr = t / TC;
+                const int py = STK ? 4 * (tr % (TR / 2)) : 4 * tr, px = 4 * (t % TC);
+                const int gy = ty0 + py, gx = tx0 + px;                            // top-left pixel of the tile
+                const int rv = a.H - gy, cv = a.W - gx;                            // rows / columns of it inside the image
+                const unsigned base = (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4);
+#pragma unroll
+                for (int ay = 0; ay < 4; ++ay)
+#pragma unroll
+                    for (int ax = 0; ax < 4; ++ax) {
+                        const float val = e == 0 ? Y[ay][ax].x : Y[ay][ax].y;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdst,
+                                                              (ay < rv && ax < cv) ? base : OOB, (ay * a.W + ax) * a.Cout * 4, 0);
+                    }
+                if (a.pooled != nullptr) {                 // MaxPool2d(2) of the tile's four windows (noise.py:22-25)
+                    const int qy = gy >> 1, qx = gx >> 1;
+                    const unsigned pbase = (unsigned)(((qy * Wp + qx) * a.Cout + cout0) * 4);
+#pragma unroll
+                    for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                        for (int wx = 0; wx < 2; ++wx) {
+                            const v2f mx = __builtin_elementwise_max(__builtin_elementwise_max(Y[2 * wy][2 * wx], Y[2 * wy][2 * wx + 1]),
+                                                                     __builtin_elementwise_max(Y[2 * wy + 1][2 * wx], Y[2 * wy + 1][2 * wx + 1]));
+                            const float val = e == 0 ? mx.x : mx.y;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool,
+                                                                  (qy + wy < Hp && qx + wx < Wp) ? pbase : OOB, (wy * Wp + wx) * a.Cout * 4, 0);
+                        }
+                }
             }
         }
-#ifdef PNP_STAMPS
-        st_er += W4T() - st_tmp;
-#endif
     }
-    (void)V4;
 #ifdef PNP_STAMPS
     {
         const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
@@ -503,7 +496,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             unsigned long long* o = g_w4_stamps + ((size_t)a.stamp_slot * W4_WGS + w) * W4_N;
             const unsigned long long te = W4T();
             o[0] = 1; o[1] = st_setup - st_t0; o[2] = st_commit; o[3] = st_trans; o[4] = st_mfma; o[5] = st_loop1 - st_loop0;
-            o[6] = st_ew; o[7] = st_er; o[8] = te - st_loop1; o[9] = te - st_t0; o[10] = (unsigned long long)nchunks;
+            o[6] = te - st_tmp; o[7] = 0; o[8] = te - st_loop1; o[9] = te - st_t0; o[10] = (unsigned long long)nchunks;
         }
     }
 #endif
@@ -511,11 +504,10 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
 
 template <int TW, int SRC, bool STK = false, int WN = 2>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
-    constexpr int CK = 8 * WN, CKP = CK + 4, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
+    constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
     constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
-    constexpr size_t lds_main = (patch_f + (size_t)36 * 32 * CKP) * sizeof(float);
-    constexpr size_t lds_out = (size_t)WN * 4 * 4 * 16 * 64 * sizeof(float);
-    constexpr size_t lds = lds_main > lds_out ? lds_main : lds_out;
+    constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) : 0;
+    constexpr size_t lds = (patch_f + (size_t)36 * 32 * CKP + lowres_f) * sizeof(float);
     static_assert(lds <= (WN == 2 ? 160 : 80) * 1024, "one (WN = 2) / two (WN = 1) workgroups per CU");
     auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN>;
     static DeviceOnce cap;
@@ -529,6 +521,7 @@ static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStr
 // `a.wpack` must be the F(4x4) pack (pack_winograd4_weights).
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
     if (!p.use || p.algo != 4 || a0.Cout % p.bn || a0.Cin % p.ck || (src_mode == SRC_UPCAT && a0.Cskip % p.ck)) return hipErrorInvalidValue;
+    if (a0.last_w != nullptr) return hipErrorInvalidValue;        // the fused last layer runs on the F(2x2) kernel
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
@@ -543,7 +536,7 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
         if (p.tw == 16 && src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT, false, 1>(a, p, s);
         return hipErrorInvalidValue;
     }
-    if (a.last_w != nullptr || p.ck != 16) return hipErrorInvalidValue;
+    if (p.ck != 16) return hipErrorInvalidValue;
     if (p.tw == 32) {
         if (src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN>(a, p, s);
         if (src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT>(a, p, s);
