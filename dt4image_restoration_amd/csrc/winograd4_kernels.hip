@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     float* const patch = smem;                             // [PH][PW][CKQ]
     float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][32 tiles][CKP]
     float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][LP] low-res source region of the chunk being staged
+    float* const rowT = lowres + LH * LW * LP;             // UPCAT: per patch row / column {offset of the two source lines in the
+    float* const colT = rowT + 4 * PH;                     // low-res region (int), their two weights}; zeros outside the image
 #ifdef PNP_STAMPS
     unsigned long long st_t0 = W4T(), st_setup = 0, st_loop0 = 0, st_commit = 0, st_trans = 0, st_mfma = 0, st_loop1 = 0, st_ew = 0, st_er = 0, st_tmp = 0;
 #endif
@@ -302,24 +304,37 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
             const int idx = tid + k * NT_;
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PW, px = pp % PW;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             if (idx < ITEMS) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
-                    const int y0 = (int)sy, x0 = (int)sx;
-                    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-                    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
-                    const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * LP + part * 4];
-                    const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * LP + part * 4];
-                    v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * LP), *reinterpret_cast<const float4*>(r0 + x1 * LP),
-                                *reinterpret_cast<const float4*>(r1 + x0 * LP), *reinterpret_cast<const float4*>(r1 + x1 * LP),
-                                1.f - lx, lx, 1.f - ly, ly);
-                }
-                put_patch((py * PW + px) * CKQ + part * 4, v);
+                const float4 rt = *reinterpret_cast<const float4*>(&rowT[4 * py]), ct = *reinterpret_cast<const float4*>(&colT[4 * px]);
+                const float* l0 = &lowres[__float_as_int(rt.x) + part * 4];
+                const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
+                const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
+                put_patch(pp * CKQ + part * 4,
+                          f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
+                                  *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
+                                  ct.z, ct.w, rt.z, rt.w));
             }
         }
     };
+    if constexpr (UP2) {
+        // the interpolation's coordinates are the same for every chunk: one table entry per patch row and column, built once
+        // (first read behind the loop-top barrier).  Pixels outside the image (the conv's zero padding) get zero weights.
+        if (tid < PH + PW) {
+            const bool isrow = tid < PH;
+            const int pq = isrow ? tid : tid - PH;
+            const int g = (isrow ? ty0 : tx0) + pq - 1;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && g < (isrow ? a.H : a.W)) {
+                const float sc = (isrow ? a.rh : a.rw) * (float)g;
+                const int i0 = (int)sc;
+                const int i1 = i0 + (i0 < (isrow ? Hs : Ws) - 1 ? 1 : 0);
+                const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
+                const int lo = isrow ? ylo : xlo, mul = isrow ? LW * LP : LP;
+                e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+            }
+            *reinterpret_cast<float4*>(&(isrow ? rowT : colT)[4 * pq]) = e;
+        }
+    }
     issue(0);
     park(0);
 
@@ -506,7 +521,7 @@ template <int TW, int SRC, bool STK = false, int WN = 2>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
     constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
     constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
-    constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) : 0;
+    constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) + 4 * (TH + 2 + TW + 2) : 0;   // + tables
     constexpr size_t lds = (patch_f + (size_t)36 * 32 * CKP + lowres_f) * sizeof(float);
     static_assert(lds <= (WN == 2 ? 160 : 80) * 1024, "one (WN = 2) / two (WN = 1) workgroups per CU");
     auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN>;
