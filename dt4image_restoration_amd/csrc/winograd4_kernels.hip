@@ -299,8 +299,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     // upsampled chunk: interpolate the patch from the parked low-res region (ATen upsample_bilinear2d, align_corners=True:
     // src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
     auto interpolate = [&]() {
-#pragma unroll 1                                           // LDS -> LDS, no prefetch registers involved: keep it a loop (registers)
-        for (int k = 0; k < NIT; ++k) {
+#pragma unroll                                             // three items' reads in flight together (the staging registers are free
+        for (int k = 0; k < NIT; ++k) {                    // here): one item at a time is a chain of LDS round trips
+            if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);
             const int idx = tid + k * NT_;
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PW, px = pp % PW;
