@@ -150,6 +150,88 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
     }
 }
 
+// ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1],
+// lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at a
+// time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).  + bias, LeakyReLU, NHWC stores (16
+// consecutive channels = 64 bytes per pixel and wave), the 2x2 max-pooled copy for the next stage from the same registers.
+template <int TW, bool STK>
+__device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&acc)[36], int n, int th, int tg, int cl, int cb,
+                                               int tx0, int ty0, bool live) {
+    constexpr int TC = TW / 4, TR = 32 / TC;
+    constexpr unsigned OOB = 0x80000000u;
+    const int cout0 = cb * 16 + cl;
+    const float bias = a.bias[cout0];
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    auto at6 = [&](v2f m0, v2f m1, v2f m2, v2f m3, v2f m4, v2f m5, v2f* t) {
+        const v2f s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        t[0] = m0 + s1 + s2;
+        t[1] = fA * d1 + fB * d2;
+        t[2] = fA2 * s1 + fB2 * s2;
+        t[3] = fA3 * d1 + fB3 * d2 + m5;
+    };
+    if (!live) return;                                     // stacked: wave th works on slice n + th, which may have stopped
+    const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.pooled != nullptr ? a.pooled + (size_t)(n + (STK ? th : 0)) * Hp * Wp * a.Cout : a.dst), 0,
+        a.pooled != nullptr ? Hp * Wp * a.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        v2f T[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            v2f m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = v2f{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]};
+            v2f t[4];
+            at6(m[0], m[1], m[2], m[3], m[4], m[5], t);
+#pragma unroll
+            for (int ay = 0; ay < 4; ++ay) T[ay][j] = t[ay];
+        }
+        v2f Y[4][4];
+#pragma unroll
+        for (int ay = 0; ay < 4; ++ay) {
+            at6(T[ay][0], T[ay][1], T[ay][2], T[ay][3], T[ay][4], T[ay][5], Y[ay]);
+#pragma unroll
+            for (int ax = 0; ax < 4; ++ax) {
+                const v2f sv = Y[ay][ax] + bias;
+                Y[ay][ax] = v2f{fmaxf(sv.x, kLeaky * sv.x), fmaxf(sv.y, kLeaky * sv.y)};
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = 16 * th + 4 * tg + 2 * rp + e;                       // tile of the M-block
+            const int tr = t / TC;
+            const int py = STK ? 4 * (tr % (TR / 2)) : 4 * tr, px = 4 * (t % TC);
+            const int gy = ty0 + py, gx = tx0 + px;                            // top-left pixel of the tile
+            const int rv = a.H - gy, cv = a.W - gx;                            // rows / columns of it inside the image
+            const unsigned base = (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4);
+#pragma unroll
+            for (int ay = 0; ay < 4; ++ay)
+#pragma unroll
+                for (int ax = 0; ax < 4; ++ax) {
+                    const float val = e == 0 ? Y[ay][ax].x : Y[ay][ax].y;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdst,
+                                                          (ay < rv && ax < cv) ? base : OOB, (ay * a.W + ax) * a.Cout * 4, 0);
+                }
+            if (a.pooled != nullptr) {                 // MaxPool2d(2) of the tile's four windows (noise.py:22-25)
+                const int qy = gy >> 1, qx = gx >> 1;
+                const unsigned pbase = (unsigned)(((qy * Wp + qx) * a.Cout + cout0) * 4);
+#pragma unroll
+                for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                    for (int wx = 0; wx < 2; ++wx) {
+                        const v2f mx = __builtin_elementwise_max(__builtin_elementwise_max(Y[2 * wy][2 * wx], Y[2 * wy][2 * wx + 1]),
+                                                                 __builtin_elementwise_max(Y[2 * wy + 1][2 * wx], Y[2 * wy + 1][2 * wx + 1]));
+                        const float val = e == 0 ? mx.x : mx.y;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool,
+                                                              (qy + wy < Hp && qx + wx < Wp) ? pbase : OOB, (wy * Wp + wx) * a.Cout * 4, 0);
+                    }
+            }
+        }
+    }
+}
+
 // STK (TW = 16, SRC_PLAIN, 16 x 16 images only - the bottom level of a 256 x 256 slice): the workgroup's 32 tiles are the
 // 4 x 4 tiles of TWO consecutive slices stacked (tile rows 0..3 -> slice n0, 4..7 -> slice n0 + 1; two 18-row halo patches
 // one above the other), so the 32-tile M-block is full instead of half padding.
@@ -429,82 +511,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     st_tmp = st_loop1;
 #endif
 
-    // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1],
-    // lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at
-    // a time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).
-    const int cout0 = cb * 16 + cl;
-    const float bias = a.bias[cout0];
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const bool live = STK ? (th == 0 ? live0 : live1) : true;                       // stacked: wave th works on slice n + th
-    auto at6 = [&](v2f m0, v2f m1, v2f m2, v2f m3, v2f m4, v2f m5, v2f* t) {
-        const v2f s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-        t[0] = m0 + s1 + s2;
-        t[1] = fA * d1 + fB * d2;
-        t[2] = fA2 * s1 + fB2 * s2;
-        t[3] = fA3 * d1 + fB3 * d2 + m5;
-    };
-    if (live) {
-        const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.pooled != nullptr ? a.pooled + (size_t)(n + (STK ? th : 0)) * Hp * Wp * a.Cout : a.dst), 0,
-            a.pooled != nullptr ? Hp * Wp * a.Cout * 4 : 0, 0x00020000);
-#pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {
-            v2f T[4][6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                v2f m[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) m[i] = v2f{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]};
-                v2f t[4];
-                at6(m[0], m[1], m[2], m[3], m[4], m[5], t);
-#pragma unroll
-                for (int ay = 0; ay < 4; ++ay) T[ay][j] = t[ay];
-            }
-            v2f Y[4][4];
-#pragma unroll
-            for (int ay = 0; ay < 4; ++ay) {
-                at6(T[ay][0], T[ay][1], T[ay][2], T[ay][3], T[ay][4], T[ay][5], Y[ay]);
-#pragma unroll
-                for (int ax = 0; ax < 4; ++ax) {
-                    const v2f sv = Y[ay][ax] + bias;
-                    Y[ay][ax] = v2f{fmaxf(sv.x, kLeaky * sv.x), fmaxf(sv.y, kLeaky * sv.y)};
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int t = 16 * th + 4 * tg + 2 * rp + e;                       // tile of the M-block
-                const int tr = t / TC;
-                const int py = STK ? 4 * (tr % (TR / 2)) : 4 * tr, px = 4 * (t % TC);
-                const int gy = ty0 + py, gx = tx0 + px;                            // top-left pixel of the tile
-                const int rv = a.H - gy, cv = a.W - gx;                            // rows / columns of it inside the image
-                const unsigned base = (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4);
-#pragma unroll
-                for (int ay = 0; ay < 4; ++ay)
-#pragma unroll
-                    for (int ax = 0; ax < 4; ++ax) {
-                        const float val = e == 0 ? Y[ay][ax].x : Y[ay][ax].y;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdst,
-                                                              (ay < rv && ax < cv) ? base : OOB, (ay * a.W + ax) * a.Cout * 4, 0);
-                    }
-                if (a.pooled != nullptr) {                 // MaxPool2d(2) of the tile's four windows (noise.py:22-25)
-                    const int qy = gy >> 1, qx = gx >> 1;
-                    const unsigned pbase = (unsigned)(((qy * Wp + qx) * a.Cout + cout0) * 4);
-#pragma unroll
-                    for (int wy = 0; wy < 2; ++wy)
-#pragma unroll
-                        for (int wx = 0; wx < 2; ++wx) {
-                            const v2f mx = __builtin_elementwise_max(__builtin_elementwise_max(Y[2 * wy][2 * wx], Y[2 * wy][2 * wx + 1]),
-                                                                     __builtin_elementwise_max(Y[2 * wy + 1][2 * wx], Y[2 * wy + 1][2 * wx + 1]));
-                            const float val = e == 0 ? mx.x : mx.y;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool,
-                                                                  (qy + wy < Hp && qx + wx < Wp) ? pbase : OOB, (wy * Wp + wx) * a.Cout * 4, 0);
-                        }
-                }
-            }
-        }
-    }
+    // ---- output transform, lane-local -----------------------------------------------------------------------------------------
+    wino4_epilogue<TW, STK>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true);
 #ifdef PNP_STAMPS
     {
         const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
@@ -516,6 +524,213 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
         }
     }
 #endif
+}
+
+// ---- PHASED variant (WN = 2, plain source) ----------------------------------------------------------------------------------
+// Same arithmetic and the same wave roles as conv3x3_wino4_kernel<TW, SRC_PLAIN, STK, 2>, different schedule.  The input
+// transform is LDS-bound (18 ds_write_b64 + 30 ds_read_b64 per thread, ~80 packed VALU instructions) and the f32 MFMAs hold the
+// SIMD's vector port, so with all eight waves in the same phase the matrix pipe idles through every transform (22 % of a
+// chunk, profiles/r02_wino4_stamps.md).  Here the two halves of the workgroup run HALF A CHUNK APART: waves 0-3 (tiles 0-15)
+// and waves 4-7 (tiles 16-31) each transform only their own 16 tiles - a wave's MFMAs read no other rows of V - so between two
+// workgroup barriers every SIMD has one wave in its MFMA phase and one in its transform:
+//     barrier | G0: T(c)      G1: M(c-1) | barrier | G0: M(c)      G1: T(c) | barrier | G0: T(c+1) ...
+// The halo patch is shared by both halves and now lives twice (chunk c+1 is parked while the lagging half still reads chunk c):
+// channel-granule planes [4][pixels][4 floats] (+4 floats per plane: the 8 x 4 (channel pair, tile) lanes of a ds_read_b64
+// group fall on 64 different banks without any pixel padding), 39 KB per copy instead of the padded 49 KB.
+template <int TW, bool STK>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino4p_kernel(const ConvArgs a) {
+    constexpr int CK = 16, CKP = 16, PPP = 4, NT_ = 512, S = 4;
+    constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
+    constexpr int TH = 4 * TR;
+    constexpr int SUBH = STK ? TH / 2 + 2 : 0;         // rows of one slice's halo patch in the stacked layout
+    constexpr int PH = STK ? 2 * SUBH : TH + 2, PW = TW + 2;
+    constexpr int NPIX = PH * PW, ITEMS = NPIX * PPP;
+    constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
+    constexpr int PLSZ = ((NPIX * 4 + 15) / 16) * 16 + 4;  // floats per channel-granule plane, = 4 (mod 16)
+    constexpr int PATCH = 4 * PLSZ;                    // floats per copy of the patch
+    constexpr int PF = 9, KEEP = 3;                    // B fragment ring, as in conv3x3_wino4_kernel
+    constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(!STK || TW == 16, "stacked slices: 16-wide tiles");
+    static_assert((2 * PATCH + 36 * PLANE) * 4 <= 160 * 1024, "two patch copies + V in one CU's LDS");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const patch = smem;                             // [2][4 granules][PLSZ]
+    float* const V = smem + 2 * PATCH;                     // [36][32 tiles][16], granules swizzled (see swz)
+#ifdef PNP_STAMPS
+    unsigned long long st_t0 = W4T(), st_setup = 0, st_loop0 = 0, st_commit = 0, st_trans = 0, st_mfma = 0, st_loop1 = 0, st_tmp = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, cq = wid & 3;                // half of the 32 tiles (the phase group), 16-channel group of this wave
+    const int th = grp;
+    const int tg = lane >> 4, cl = lane & 15;              // MFMA lane = (k / row group tg, column / row cl)
+
+    const int ny = a.Cout / 64;
+    const int bid = blockIdx.x;
+    const int grpb = bid / (8 * ny), rem = bid % (8 * ny);
+    const int cby = rem >> 3;                              // this workgroup's block of 64 channels
+    int bt = grpb * 8 + (rem & 7);                         // spatial tile index (XCD-aware order, see conv3x3_wino4_kernel)
+    if (bt >= a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N)) return;
+    const int tx0 = (bt % a.tilesX) * TW;
+    bt /= a.tilesX;
+    const int ty0 = (bt % a.tilesY) * TH;
+    const int n = STK ? 2 * (bt / a.tilesY) : bt / a.tilesY;               // first (or only) slice of this workgroup
+    const int nsl = STK ? (n + 1 < a.N ? 2 : 1) : 1;                       // slices this workgroup holds
+    const bool live0 = !(a.tact != nullptr && a.tact[n] > 0.5f);
+    const bool live1 = STK && nsl == 2 && !(a.tact != nullptr && a.tact[n + 1] > 0.5f);
+    if (!live0 && !live1) return;
+    const int cb = cby * 4 + cq;                           // this wave's 16-channel block
+    const int nchunks = a.Cin / CK;
+
+    // staging addresses, once (see conv3x3_wino4_kernel): item idx = (pixel, channel granule), granule fastest
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.src0 + (size_t)n * a.H * a.W * a.Cin), 0, nsl * a.H * a.W * a.Cin * 4, 0x00020000);
+    unsigned voff[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = tid + k * NT_;
+        const int part = idx % PPP, pp = idx / PPP;
+        const int py = pp / PW, px = pp % PW;
+        const int sub = STK ? py / SUBH : 0;                               // stacked: which of the two slices
+        const int gy = STK ? py % SUBH - 1 : ty0 + py - 1, gx = tx0 + px - 1;
+        voff[k] = (idx < ITEMS && sub < nsl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                      ? (unsigned)((((sub * a.H + gy) * a.W + gx) * a.Cin + part * 4) * 4) : OOB;
+    }
+    const int ldst = (tid & 3) * PLSZ + (tid >> 2) * 4;    // LDS slot of item 0; item k is 128 pixels (512 floats) further
+    float4 raw[NIT];
+    auto issue = [&](int c) {
+        const int soff = c * CK * 4;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
+    };
+    auto park = [&](int c) {                               // registers -> copy (c & 1) of the patch
+        float* const dst = patch + (c & 1) * PATCH + ldst;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (tid + k * NT_ < ITEMS) *reinterpret_cast<float4*>(&dst[k * (NT_ / PPP) * 4]) = raw[k];
+    };
+
+    // this thread's transform item: tile t16 of its half's 16 tiles, channels [2*hc, 2*hc+2), frequency column group tj
+    // (waves 0-1 of the half: columns 0..2, waves 2-3: columns 3..5; all six rows)
+    auto swz = [](int t16, int g) { return g ^ ((4 - (t16 >> 2)) & 3); };
+    const int tgi = tid & 255;
+    const int hc = tgi & 7, t16 = (tgi >> 3) & 15;
+    const int tj = (wid >> 1) & 1;
+    const int tq = 16 * grp + t16;
+    const int trow = tq / TC;                                                  // tile row; stacked: rows 0..3 / 4..7 = slice 0 / 1
+    const int wrow = STK ? (trow / (TR / 2)) * SUBH + 4 * (trow % (TR / 2)) : 4 * trow;
+    const int win = (hc >> 1) * PLSZ + (wrow * PW + 4 * (tq % TC)) * 4 + 2 * (hc & 1);   // top-left of the 6x6 window, copy 0
+    const int vout = tq * CKP + 4 * swz(t16, hc >> 1) + 2 * (hc & 1);          // this item's slot in every frequency plane
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const size_t stream = (size_t)nchunks * 36 * 64 + kW4Tail / S;                // fragments per 16-channel block's stream
+    const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * stream + lane;
+    float4 bq[PF];
+#pragma unroll
+    for (int p = 0; p < KEEP; ++p) bq[p] = bptr[p * 64];
+    const int aoff = (16 * th + cl) * CKP + 4 * swz(cl, tg);                      // this lane's fragment of V[0]
+
+    // prologue: both halves park their share of chunk 0; the lagging half also of chunk 1 (its in-loop parks run one chunk
+    // further ahead, see below)
+    issue(0);
+    park(0);
+    if (grp == 1 && nchunks > 1) { issue(1); park(1); }
+#ifdef PNP_STAMPS
+    st_setup = W4T();
+    st_loop0 = st_setup;
+#endif
+    if (grp == 1) __syncthreads();                         // the lagging half starts one phase late
+    for (int c = 0; c < nchunks; ++c) {
+#ifdef PNP_STAMPS
+        st_tmp = W4T();
+#endif
+        __syncthreads();                                   // chunk c is parked by everyone; this half's MFMAs of chunk c-1 are done
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_commit += t - st_tmp; st_tmp = t; }
+#endif
+        // ---- input transform of this half's 16 tiles (its partner waves on the SIMDs are in their MFMA phase: the few VALU
+        // instructions of the transform go first)
+        __builtin_amdgcn_s_setprio(3);
+        {
+            const float* const w = patch + (c & 1) * PATCH + win;
+            if (tj == 0) wino4_input_transform<0, PW, 4, PLANE>(w, V + vout);
+            else wino4_input_transform<1, PW, 4, PLANE>(w, V + vout);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4* bp = bptr + (size_t)c * 36 * 64;
+#pragma unroll
+        for (int p = KEEP; p < PF; ++p) bq[p] = bp[p * 64];
+        // Staging runs ahead of the TRANSFORMS, and the lagging half transforms chunk c a phase after the leading half: the
+        // leading half parks chunk c+1 after its MFMAs of chunk c, the lagging half chunk c+2 (both land in a copy whose last
+        // reader - the lagging half's transform - is at least one barrier back, and a full phase before their first reader).
+        const int nx = c + 1 + grp;
+        if (nx < nchunks) issue(nx);
+        __syncthreads();
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_trans += t - st_tmp; st_tmp = t; }
+#endif
+
+        // ---- 36 GEMMs per wave: A from V (LDS), B from the packed U stream (L2), 4 MFMAs per frequency -----------------------
+        float4 ar[3];
+        ar[0] = *reinterpret_cast<const float4*>(&V[aoff]);
+        ar[1] = *reinterpret_cast<const float4*>(&V[PLANE + aoff]);
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) {
+            if (xi + 2 < 36) ar[(xi + 2) % 3] = *reinterpret_cast<const float4*>(&V[(xi + 2) * PLANE + aoff]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a0 = ar[xi % 3], b0 = bq[xi % PF];
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[xi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (xi + PF < 36 + KEEP) bq[xi % PF] = bp[(xi + PF) * 64];
+        }
+#ifdef PNP_STAMPS
+        { const unsigned long long t = W4T(); st_mfma += t - st_tmp; }
+#endif
+        if (nx < nchunks) park(nx);
+    }
+    if (grp == 0) __syncthreads();                         // pairs with the lagging half's last barrier
+#ifdef PNP_STAMPS
+    st_loop1 = W4T();
+    st_tmp = st_loop1;
+#endif
+
+    // ---- output transform, lane-local (as conv3x3_wino4_kernel) ---------------------------------------------------------------
+    wino4_epilogue<TW, STK>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true);
+#ifdef PNP_STAMPS
+    {
+        const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
+        if (tid == 0 && w >= 0 && w < W4_WGS && a.stamp_slot < W4_SLOTS) {
+            unsigned long long* o = g_w4_stamps + ((size_t)a.stamp_slot * W4_WGS + w) * W4_N;
+            const unsigned long long te = W4T();
+            o[0] = 1; o[1] = st_setup - st_t0; o[2] = st_commit; o[3] = st_trans; o[4] = st_mfma; o[5] = st_loop1 - st_loop0;
+            o[6] = te - st_tmp; o[7] = 0; o[8] = te - st_loop1; o[9] = te - st_t0; o[10] = (unsigned long long)nchunks;
+        }
+    }
+#endif
+}
+
+template <int TW, bool STK>
+static hipError_t launch_wino4p_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
+    constexpr int TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
+    constexpr int NPIX = (STK ? TH + 4 : TH + 2) * (TW + 2);
+    constexpr int PLSZ = ((NPIX * 4 + 15) / 16) * 16 + 4;
+    constexpr size_t lds = ((size_t)2 * 4 * PLSZ + (size_t)36 * 32 * 16) * sizeof(float);
+    auto kern = conv3x3_wino4p_kernel<TW, STK>;
+    static DeviceOnce cap;
+    if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
+    const int ntiles = p.tiles_x * p.tiles_y * (STK ? (a.N + 1) / 2 : a.N), ny = a.Cout / 64;
+    dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * ny));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
 }
 
 template <int TW, int SRC, bool STK = false, int WN = 2>
@@ -553,6 +768,14 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
         return hipErrorInvalidValue;
     }
     if (p.ck != 16) return hipErrorInvalidValue;
+    if (p.phased && src_mode == SRC_PLAIN) {               // the two tile halves half a chunk apart (conv3x3_wino4p_kernel)
+        if (p.tw == 32 && !p.stack) return launch_wino4p_inst<32, false>(a, p, s);
+        if (p.tw == 16) {
+            if (p.stack) return a.H == 16 && a.W == 16 ? launch_wino4p_inst<16, true>(a, p, s) : hipErrorInvalidValue;
+            return launch_wino4p_inst<16, false>(a, p, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.tw == 32) {
         if (src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN>(a, p, s);
         if (src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT>(a, p, s);

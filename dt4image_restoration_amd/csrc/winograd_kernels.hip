@@ -90,6 +90,7 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
         f.tiles_y = (H + f.th - 1) / f.th;
         f.stack = (W == 16 && H == 16) ? 1 : 0;             // 16 x 16 images: two slices per 32-tile workgroup
         if (f.stack && Cout == 32) return p;
+        f.phased = (f.bn == 64 && src_mode == SRC_PLAIN && !t.no_f4_phased) ? 1 : 0;
         const long blocks = (long)f.tiles_x * f.tiles_y * (f.stack ? (N + 1) / 2 : N) * (Cout / f.bn);
         f.use = blocks >= t.wino_min_blocks;
         if (f.use) return f;
