@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4p_kernel(const ConvArgs a
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr int PLSZ = ((NPIX * 4 + 15) / 16) * 16 + 4;  // floats per channel-granule plane, = 4 (mod 16)
     constexpr int PATCH = 4 * PLSZ;                    // floats per copy of the patch
-    constexpr int PF = 9, KEEP = 3;                    // B fragment ring, as in conv3x3_wino4_kernel
+    constexpr int PF = 12, KEEP = 3;                   // B fragment ring (conv3x3_wino4_kernel), deeper: one MFMA wave per SIMD at a time
     constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
     constexpr unsigned OOB = 0x80000000u;
     static_assert(!STK || TW == 16, "stacked slices: 16-wide tiles");
