@@ -19,6 +19,8 @@ struct Tuning {
     int f4_min_cin = 32;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
+    int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
+                                  // 64-channel-block layer on 16-tile M-blocks
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
                                   // needs a chip-filling batch to beat the three-launch path: 64.1 vs 78.8 us at 256 slices, 48.9 vs 34.9 at 64)
@@ -89,6 +91,7 @@ struct WinoPlan {
     int algo;          // 1: F(2x2,3x3) (winograd_kernels.hip), 4: F(4x4,3x3) (winograd4_kernels.hip)
     int tw, th, bn, wm, wn, ck, tiles_x, tiles_y;
     int stack;         // F(4x4) on 16 x 16 images: two slices stacked into one 32-tile workgroup
+    int mt;            // F(4x4): tiles per workgroup (32, or 16 = two independent 4-wave workgroups per CU)
     int phased;        // F(4x4), 64-channel blocks, plain source: the two tile halves run half a chunk apart (conv3x3_wino4p_kernel)
 };
 // `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)

@@ -154,10 +154,10 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
 // lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at a
 // time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).  + bias, LeakyReLU, NHWC stores (16
 // consecutive channels = 64 bytes per pixel and wave), the 2x2 max-pooled copy for the next stage from the same registers.
-template <int TW, bool STK>
+template <int TW, bool STK, int MT = 32>
 __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&acc)[36], int n, int th, int tg, int cl, int cb,
                                                int tx0, int ty0, bool live) {
-    constexpr int TC = TW / 4, TR = 32 / TC;
+    constexpr int TC = TW / 4, TR = MT / TC;
     constexpr unsigned OOB = 0x80000000u;
     const int cout0 = cb * 16 + cl;
     const float bias = a.bias[cout0];
@@ -238,17 +238,21 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
 // WN = 2: 8 waves, 64 output channels, 16-channel chunks, one workgroup per CU (the layout described above).
 // WN = 1 (Cout = 32, the full-resolution layers): 4 waves = 2 tile halves x 2 groups of 16 channels, 8-channel chunks (two
 // MFMAs per frequency, b64 fragments), 61 KB of LDS so that TWO workgroups share a CU.
-template <int TW, int SRC, bool STK = false, int WN = 2>
-__global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
-    constexpr int CK = 8 * WN, CKP = CK, LP = CK + 4, PPP = CK / 4, NT_ = 256 * WN;   // CKP / LP: pixel stride of V / the low-res region
+// MT = 16 (with WN = 2): the M-block is 16 tiles - 4 waves, one per 16-channel group, 64-75 KB of LDS - so that TWO independent
+// workgroups share a CU and one's transforms, barriers, interpolation and epilogue run under the other's MFMAs without any
+// lockstep between them (the upsample + concat layers; 16 x 16 images need no stacking: 4 x 4 tiles are one slice).
+template <int TW, int SRC, bool STK = false, int WN = 2, int MT = 32>
+__global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
+    constexpr int CK = 8 * WN, CKP = CK, LP = CK + 4, PPP = CK / 4, NT_ = 8 * MT * WN;   // CKP / LP: pixel stride of V / the low-res region
     constexpr int CKQ = WN == 2 ? CK + 4 : CK + 2;     // patch pixel stride (floats): b64 window reads conflict-free for both
     constexpr int HCN = CK / 2;                        // 2-channel units per pixel
-    constexpr int TC = TW / 4, TR = 32 / TC;           // tiles per row / rows of tiles in the 32-tile M-block
+    constexpr int TC = TW / 4, TR = MT / TC;           // tiles per row / rows of tiles in the MT-tile M-block
     constexpr int TH = 4 * TR;
     constexpr int SUBH = STK ? TH / 2 + 2 : 0;         // rows of one slice's halo patch in the stacked layout
     constexpr int PH = STK ? 2 * SUBH : TH + 2, PW = TW + 2;
     constexpr int ITEMS = PH * PW * PPP;
-    static_assert(!STK || (TW == 16 && SRC == SRC_PLAIN && WN == 2), "stacked slices: 16-wide tiles, plain source");
+    static_assert(!STK || (TW == 16 && SRC == SRC_PLAIN && WN == 2 && MT == 32), "stacked slices: 16-wide tiles, plain source");
+    static_assert(MT == 32 || (MT == 16 && WN == 2), "16-tile M-blocks: 64-channel workgroups only");
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr bool UP2 = SRC == SRC_UPCAT;
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
@@ -256,17 +260,17 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
     constexpr int NRAW = (UP2 && NITL > NIT) ? NITL : NIT;
     constexpr int S = CK / 4;                          // MFMAs (4 channels each) per frequency and chunk
-    constexpr int PF = WN == 2 ? 9 : 12;               // B fragments in flight in the MFMA loop (must divide 36: slots line up
+    constexpr int PF = WN == 2 ? 9 : 12;                              // B fragments in flight in the MFMA loop (must divide 36: slots line up
                                                        // across chunks) ...
     constexpr int KEEP = 3;                            // ... of which only the first KEEP are loaded across the chunk boundary (the
                                                        // input transform needs the registers); the rest go out after the transform
-    constexpr int PLANE = 32 * CKP;                    // floats per frequency plane of V
+    constexpr int PLANE = MT * CKP;                    // floats per frequency plane of V
     static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
-    static_assert(36 % PF == 0 && 32 * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
+    static_assert(36 % PF == 0 && MT * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const patch = smem;                             // [PH][PW][CKQ]
-    float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][32 tiles][CKP]
+    float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][MT tiles][CKP]
     float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][LP] low-res source region of the chunk being staged
     float* const rowT = lowres + LH * LW * LP;             // UPCAT: per patch row / column {offset of the two source lines in the
     float* const colT = rowT + 4 * PH;                     // low-res region (int), their two weights}; zeros outside the image
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cq = wid >> 1, th = wid & 1;                 // this wave's 16-channel group and half of the 32 tiles
+    const int cq = wid / (MT / 16), th = wid % (MT / 16);  // this wave's 16-channel group and 16-tile part of the M-block
     const int tg = lane >> 4, cl = lane & 15;              // MFMA lane = (k / row group tg, column / row cl)
 
     // XCD-aware decode: the channel groups of one spatial tile run back to back on the same XCD (blocks b and b + 8 share
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     auto interpolate = [&]() {
 #pragma unroll                                             // three items' reads in flight together (the staging registers are free
         for (int k = 0; k < NIT; ++k) {                    // here): one item at a time is a chain of LDS round trips
-            if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);
+            if (k % (MT == 16 ? 2 : 3) == 0) __builtin_amdgcn_sched_barrier(0);
             const int idx = tid + k * NT_;
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PW, px = pp % PW;
@@ -430,8 +434,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
     // granule g+1}: granule position = g ^ m[tile / 4], m = {0, 3, 2, 1};  WN = 1, ds_read_b64 in 32-lane groups {16 tiles x
     // 2 granules}: position = g ^ 2 * (tile / 8).
     auto swz = [](int t16, int g) { return WN == 2 ? (g ^ ((4 - (t16 >> 2)) & 3)) : (g ^ ((t16 >> 3) << 1)); };
-    const int hc = tid % HCN, tq = (tid / HCN) & 31;
-    const int tj = wid / (2 * WN);
+    const int hc = tid % HCN, tq = (tid / HCN) % MT;
+    const int tj = wid / (NT_ / 128);
     const int trow = tq / TC;                                                  // tile row; stacked: rows 0..3 / 4..7 = slice 0 / 1
     const int wrow = STK ? (trow / (TR / 2)) * SUBH + 4 * (trow % (TR / 2)) : 4 * trow;
     const int win = (wrow * PW + 4 * (tq % TC)) * CKQ + 2 * hc;                // top-left of tile tq's 6x6 input window
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wino4_kernel(const ConvAr
 #endif
 
     // ---- output transform, lane-local -----------------------------------------------------------------------------------------
-    wino4_epilogue<TW, STK>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true);
+    wino4_epilogue<TW, STK, MT>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true);
 #ifdef PNP_STAMPS
     {
         const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
@@ -733,19 +737,20 @@ static hipError_t launch_wino4p_inst(const ConvArgs& a, const WinoPlan& p, hipSt
     return hipGetLastError();
 }
 
-template <int TW, int SRC, bool STK = false, int WN = 2>
+template <int TW, int SRC, bool STK = false, int WN = 2, int MT = 32>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
-    constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = 32 / TC, TH = 4 * TR;
+    constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = MT / TC, TH = 4 * TR;
     constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
     constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) + 4 * (TH + 2 + TW + 2) : 0;   // + tables
-    constexpr size_t lds = (patch_f + (size_t)36 * 32 * CKP + lowres_f) * sizeof(float);
-    static_assert(lds <= (WN == 2 ? 160 : 80) * 1024, "one (WN = 2) / two (WN = 1) workgroups per CU");
-    auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN>;
+    constexpr size_t lds = (patch_f + (size_t)36 * MT * CKP + lowres_f) * sizeof(float);
+    static_assert(lds <= (WN == 2 && MT == 32 ? 160 : 80) * 1024, "one (8 waves) / two (4 waves) workgroups per CU");
+    if (p.th != TH || p.tw != TW) return hipErrorInvalidValue;
+    auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN, MT>;
     static DeviceOnce cap;
     if (hipError_t e = raise_lds_cap((const void*)kern, (int)lds, cap); e != hipSuccess) return e;
     const int ntiles = p.tiles_x * p.tiles_y * (STK ? (a.N + 1) / 2 : a.N), ny = a.Cout / (32 * WN);
     dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * ny));
-    hipLaunchKernelGGL(kern, grid, dim3(256 * WN), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(8 * MT * WN), lds, s, a);
     return hipGetLastError();
 }
 
@@ -768,6 +773,14 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
         return hipErrorInvalidValue;
     }
     if (p.ck != 16) return hipErrorInvalidValue;
+    if (p.mt == 16) {                                      // 16-tile M-blocks: two independent 4-wave workgroups per CU
+        if (p.stack) return hipErrorInvalidValue;
+        if (p.tw == 32 && src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN, false, 2, 16>(a, p, s);
+        if (p.tw == 32 && src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT, false, 2, 16>(a, p, s);
+        if (p.tw == 16 && src_mode == SRC_PLAIN) return launch_wino4_inst<16, SRC_PLAIN, false, 2, 16>(a, p, s);
+        if (p.tw == 16 && src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT, false, 2, 16>(a, p, s);
+        return hipErrorInvalidValue;
+    }
     if (p.phased && src_mode == SRC_PLAIN) {               // the two tile halves half a chunk apart (conv3x3_wino4p_kernel)
         if (p.tw == 32 && !p.stack) return launch_wino4p_inst<32, false>(a, p, s);
         if (p.tw == 16) {
