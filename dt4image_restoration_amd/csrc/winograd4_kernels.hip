@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) convolution for the K-heavy denoiser layers (Cin >= 128) on gfx950 (MI355X).
+// Winograd F(4x4, 3x3) convolution for the denoiser layers with Cin >= 32 (25 of the 26 conv3x3 layers) on gfx950 (MI355X).
 //
 // Same operator as conv3x3_winograd_kernel / conv3x3_mfma_kernel (conv3x3 s1 p1 + bias + LeakyReLU(0.2),
 // /root/reference/evaluation/noise.py:75-98, the stage's bilinear-upsample+concat input transform applied while staging),
@@ -24,6 +24,13 @@
 // met in LDS: 256 ds_write_b32 per lane, ~15k cycles per workgroup - 40 % of a 32 -> 32 layer's lifetime,
 // profiles/r02_wino4_stamps.md).  + bias, LeakyReLU, NHWC stores (16 consecutive channels = 64 bytes per pixel and wave, the
 // neighbouring wave writes the other half of the line) and the 2x2 max-pooled copy for the next stage from the same registers.
+//
+// Three schedules of the same arithmetic (winograd_plan picks per layer):
+//   conv3x3_wino4_kernel<.., WN = 2, MT = 32>  8 waves in step (barrier - transform - barrier - MFMAs), one workgroup per CU
+//   conv3x3_wino4p_kernel                      8 waves, the two tile halves half a chunk apart: one wave of every SIMD is in its
+//                                              MFMA phase while the other transforms (plain layers with Cin >= 128)
+//   conv3x3_wino4_kernel<.., MT = 16 / WN = 1> 4-wave workgroups (16 tiles x 64 channels / 32 tiles x 32 channels), two
+//                                              independent ones per CU (upsample + concat layers, Cin <= 64, Cout = 32)
 #include "pnp_internal.h"
 #include "conv_staging.h"
 #include <type_traits>

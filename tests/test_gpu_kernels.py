@@ -184,12 +184,20 @@ def test_winograd_path_matches_oracle_per_stage(sd_np, n, h, w, monkeypatch):
 @pytest.mark.parametrize("n,h,w,min_cin", [(2, 128, 128, 128), (2, 96, 112, 128), (1, 144, 64, 128), (1, 256, 256, 128), (3, 128, 64, 64),
                                            (3, 256, 256, 64),       # 16 x 16 bottom level: two slices stacked per workgroup (odd batch)
                                            (2, 128, 128, 32), (1, 80, 48, 32)])   # + the Cout = 32 / Cin = 32 layers (4-wave variant)
-def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, monkeypatch):
+@pytest.mark.parametrize("schedule", ["default", "in-step", "independent"])
+def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, schedule, monkeypatch):
     """F(4x4,3x3) (winograd4_kernels.hip, points 0, +-3/4, +-3/2, inf) on every layer it can take - workgroup gate lifted so
     small and ragged sizes run it (partial 4x4 tiles, 16- and 32-wide tile variants, upsample+concat sources, pooled copies
-    written by its epilogue) - per stage against the oracle.  min_cin = 64 also sends the 64-channel layers through it."""
+    written by its epilogue) - per stage against the oracle.  min_cin = 64 also sends the 64-channel layers through it.
+    schedule: the per-layer default mix; every 64-channel-block layer on the 8-wave in-step kernel (incl. the stacked 16 x 16
+    level); every one on 16-tile M-blocks (two independent workgroups per CU)."""
     monkeypatch.setenv("PNP_WINO_MIN_BLOCKS", "1")
     monkeypatch.setenv("PNP_WINO_F4_MIN_CIN", str(min_cin))
+    if schedule == "in-step":
+        monkeypatch.setenv("PNP_NO_WINO_F4_PHASED", "1")
+        monkeypatch.setenv("PNP_WINO_F4_MT16", "1")
+    elif schedule == "independent":
+        monkeypatch.setenv("PNP_WINO_F4_MT16", "3")
     e = _engine(n, h, w, sd_np, keep_stages=True)
     algos = e.conv_algorithms()
     assert sum(1 for v in algos if v == 4) >= (9 if min_cin <= 64 and min(h, w) >= 128 else 1), algos
