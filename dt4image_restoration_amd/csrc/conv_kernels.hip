@@ -569,6 +569,7 @@ Tuning tuning_from_env() {
     if (const char* v = getenv("PNP_WINO_F4_MIN_CIN")) t.f4_min_cin = atoi(v);
     t.no_f4 = getenv("PNP_NO_WINO_F4") != nullptr;
     t.no_f4_phased = getenv("PNP_NO_WINO_F4_PHASED") != nullptr;
+    t.no_f4_fused_last = getenv("PNP_NO_F4_FUSED_LAST") != nullptr;
     if (const char* v = getenv("PNP_WINO_F4_MT16")) t.f4_mt16 = atoi(v);
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;

@@ -296,10 +296,11 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             if (L.src == SRC_POOL && (lh * 2) % 2 == 0 && (e->wino[li - 1] || conv3x3_pooled_output_ok(e->cplan[li - 1])))
                 src_mode = SRC_PLAIN;
             e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, e->tune);
-            if (li == 26 && e->wplan[li].algo == 4 && !(cfg->flags & PNP_FLAG_KEEP_STAGES)) {
-                // up4.conv-2 carries the fused last layer (1x1 conv + residual + clamp) in its epilogue: the F(2x2) kernel walks
-                // whole pixels there (coalesced 4-byte stores); the F(4x4) epilogue's (window, 4 channels) ownership needs a
-                // cross-lane reduction per pixel and measured 0.582 against 0.489 ms
+            if (li == 26 && e->wplan[li].algo == 4 && !(cfg->flags & PNP_FLAG_KEEP_STAGES) &&
+                (e->tune.no_f4_fused_last || e->wplan[li].bn != 32 || e->wplan[li].mt != 32)) {
+                // up4.conv-2 carries the fused last layer (1x1 conv + residual + clamp) in its epilogue: the F(4x4) kernel's
+                // 32-channel variant has it (DPP reduce-scatter over a pixel's channels); PNP_NO_F4_FUSED_LAST puts the layer
+                // back on the F(2x2) kernel, which walks whole pixels there
                 Tuning t2 = e->tune;
                 t2.no_f4 = true;
                 e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, t2);

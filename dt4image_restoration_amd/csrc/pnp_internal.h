@@ -18,6 +18,7 @@ struct Tuning {
     bool no_wino = false;         // PNP_NO_WINOGRAD
     int f4_min_cin = 32;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
+    bool no_f4_fused_last = false;// PNP_NO_F4_FUSED_LAST: up4.conv-2 (+ fused last layer) on the F(2x2) kernel
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
     int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
                                   // 64-channel-block layer on 16-tile M-blocks

@@ -161,9 +161,28 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
 // lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at a
 // time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).  + bias, LeakyReLU, NHWC stores (16
 // consecutive channels = 64 bytes per pixel and wave), the 2x2 max-pooled copy for the next stage from the same registers.
-template <int TW, bool STK, int MT = 32>
+// FUSE (the 32-channel variant, 4 waves = 2 tile halves x 2 channel groups) and a.last_w set: the denoiser's last layer (1x1 conv
+// 32 -> 1, + image channel, clamp; noise.py:67,130-133,164) is applied here and this conv's own 32-channel output is never
+// written.  A pixel's 32 channels sit in the 16 lanes of a DPP row (x 2 waves): reduce-scatter over the row - four steps of
+// "keep the half of the values my lane bit selects, add the partner's" with row_mirror / row_half_mirror / quad_perm, after
+// which lane cl holds pixel cl of each of its 4 tiles - then the two channel-group waves meet in LDS (`xch`, 2 KB).
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int H, int CTRL>
+__device__ __forceinline__ void row_reduce_scatter_step(v2f* P, bool bit) {
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const v2f lo = P[i], hi = P[i + H];
+        const v2f keep = bit ? hi : lo, send = bit ? lo : hi;
+        P[i] = v2f{keep.x + dpp_xchg<CTRL>(send.x), keep.y + dpp_xchg<CTRL>(send.y)};
+    }
+}
+
+template <int TW, bool STK, int MT = 32, bool FUSE = false>
 __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&acc)[36], int n, int th, int tg, int cl, int cb,
-                                               int tx0, int ty0, bool live) {
+                                               int tx0, int ty0, bool live, float* xch = nullptr) {
     constexpr int TC = TW / 4, TR = MT / TC;
     constexpr unsigned OOB = 0x80000000u;
     const int cout0 = cb * 16 + cl;
@@ -177,6 +196,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
         t[3] = fA3 * d1 + fB3 * d2 + m5;
     };
     if (!live) return;                                     // stacked: wave th works on slice n + th, which may have stopped
+    const bool fused = FUSE && a.last_w != nullptr;        // (uniform over the workgroup)
+    v2f part[2];                                           // fused: pixel cl of tiles 4 tg + (0,1), (2,3), summed over this wave's channels
     const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
@@ -203,6 +224,20 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
             for (int ax = 0; ax < 4; ++ax) {
                 const v2f sv = Y[ay][ax] + bias;
                 Y[ay][ax] = v2f{fmaxf(sv.x, kLeaky * sv.x), fmaxf(sv.y, kLeaky * sv.y)};
+            }
+        }
+        if constexpr (FUSE) {
+            if (fused) {
+                const float wl = a.last_w[cout0];
+                v2f P[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P[i] = Y[i >> 2][i & 3] * wl;
+                row_reduce_scatter_step<8, 0x140>(P, (cl & 8) != 0);           // row_mirror: lane ^ 15
+                row_reduce_scatter_step<4, 0x141>(P, (cl & 4) != 0);           // row_half_mirror: lane ^ 7
+                row_reduce_scatter_step<2, 0x1B>(P, (cl & 2) != 0);            // quad_perm [3,2,1,0]: lane ^ 3
+                row_reduce_scatter_step<1, 0xB1>(P, (cl & 1) != 0);            // quad_perm [1,0,3,2]: lane ^ 1
+                part[rp] = P[0];
+                continue;
             }
         }
 #pragma unroll
@@ -234,6 +269,29 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool,
                                                               (qy + wy < Hp && qx + wx < Wp) ? pbase : OOB, (wy * Wp + wx) * a.Cout * 4, 0);
                     }
+            }
+        }
+    }
+    if constexpr (FUSE) {
+        if (fused) {
+            const int cq = cb & 1, lane = 16 * tg + cl;
+            float4* const x4 = reinterpret_cast<float4*>(xch) + th * 64 + lane;
+            if (cq == 1) *x4 = make_float4(part[0].x, part[0].y, part[1].x, part[1].y);
+            __syncthreads();                               // (patch space: nobody reads it after the last chunk's transform)
+            if (cq == 0) {
+                const float4 o = *x4;
+                const float sum[4] = {part[0].x + o.x, part[0].y + o.y, part[1].x + o.z, part[1].y + o.w};
+                const float lb = a.last_b[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * th + 4 * tg + r;
+                    const int gy = ty0 + 4 * (t / TC) + (cl >> 2), gx = tx0 + 4 * (t % TC) + (cl & 3);
+                    if (gy < a.H && gx < a.W) {
+                        const size_t qx = ((size_t)n * a.H + gy) * a.W + gx;
+                        const float img = a.last_ximg != nullptr ? a.last_ximg[qx] : (a.last_z[qx].x - a.last_u[qx].x);
+                        a.last_out[qx] = fminf(fmaxf(img + sum[r] + lb, 0.f), 1.f);
+                    }
+                }
             }
         }
     }
@@ -523,7 +581,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
 #endif
 
     // ---- output transform, lane-local -----------------------------------------------------------------------------------------
-    wino4_epilogue<TW, STK, MT>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true);
+    wino4_epilogue<TW, STK, MT, WN == 1 && MT == 32 && SRC == SRC_PLAIN>(a, acc, n, th, tg, cl, cb, tx0, ty0, STK ? (th == 0 ? live0 : live1) : true, smem);
 #ifdef PNP_STAMPS
     {
         const int w = (int)blockIdx.x - (int)(gridDim.x / 2);
@@ -764,7 +822,7 @@ static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStr
 // `a.wpack` must be the F(4x4) pack (pack_winograd4_weights).
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
     if (!p.use || p.algo != 4 || a0.Cout % p.bn || a0.Cin % p.ck || (src_mode == SRC_UPCAT && a0.Cskip % p.ck)) return hipErrorInvalidValue;
-    if (a0.last_w != nullptr) return hipErrorInvalidValue;        // the fused last layer runs on the F(2x2) kernel
+    if (a0.last_w != nullptr && !(p.bn == 32 && p.mt == 32 && src_mode == SRC_PLAIN)) return hipErrorInvalidValue;   // fused last layer: 32-channel variant
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
