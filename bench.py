@@ -286,7 +286,7 @@ def main():
             "slice_iterations_per_sec": round(value * n, 2),
             "psnr_mean_db": round(float(psnr_all.mean()), 4),
             "roofline": {
-                "kernel": "conv3x3_wino4_kernel + conv3x3_winograd_kernel + conv3x3_mfma_kernel (26 launches/step: all denoiser conv3x3 layers "
+                "kernel": "conv3x3_wino4_kernel + conv3x3_wino4p_kernel + conv3x3_winograd_kernel + conv3x3_mfma_kernel (26 launches/step: all denoiser conv3x3 layers "
                           f"with Cin>=32; {sum(1 for v in algos if v == 4)} on Winograd F(4x4,3x3), {sum(1 for v in algos if v == 1)} "
                           f"on Winograd F(2x2,3x3), {sum(1 for v in algos if v == 0)} direct)",
                 "bound": "mfma", "achieved": round(executed, 3) if executed else None, "peak": mfma_peak,
