@@ -345,6 +345,7 @@ def main():
             with open(args.dump_layers, "w") as f:
                 json.dump(rows, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
+            args.cpu_slices = min(args.cpu_slices, n)              # the sample is a prefix of the batch
             mu_c, sg_c = synthetic.param_table(n, total_iters, seed=77)
             cb, cdata, chist = cpu_baseline(sd_np, h, w, n, args.cpu_slices, args.cpu_iters, mu_c, sg_c, args.accel)
             # PSNR delta vs the oracle on the same slices / same parameter prefix (fresh small engine)
