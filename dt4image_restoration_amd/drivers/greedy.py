@@ -19,6 +19,11 @@ encoder is a pure per-image function, so each observation is encoded ONCE when i
 (`PolicyContext.ee`) and both forwards read the cached embeddings - 1 encoder image per slice and step instead of 12.
 `sync_every` spaces out the only host synchronisation of the loop (the all-stopped check).
 
+`use_graphs` (default on a GPU): the policy side of a steady-state step - the observation's state encoder, and the two transformer
+forwards over the 6-step window - is ~175 kernels of a few microseconds each; they are captured ONCE per batch size in two hipGraphs
+(`torch.cuda.CUDAGraph`) over static window buffers and replayed (same kernels, same arithmetic; the first `ctx` steps of an
+episode, whose read positions move, stay eager).
+
 `rollout_rows` is the same loop with a per-row clock (rows of one batch at different episode times), which is what a
 batched tree search needs: the nodes selected in different images sit at different depths.
 """
@@ -59,7 +64,8 @@ class PolicyContext:
 
 class GreedyEvaluator:
     def __init__(self, model, env, action_dim: int = 3, max_timesteps: int = 30, block_size: int = 18,
-                 device_type="cuda", cache_state_embeddings: bool = True, sync_every: int = 1):
+                 device_type="cuda", cache_state_embeddings: bool = True, sync_every: int = 1,
+                 use_graphs: Optional[bool] = None):
         self.model = model.to(device_type).eval()
         self.env = env
         self.action_dim = action_dim
@@ -73,6 +79,10 @@ class GreedyEvaluator:
         self.device = torch.device(device_type)
         self.cache_state_embeddings = cache_state_embeddings
         self.sync_every = max(1, int(sync_every))
+        # hipGraph replay of the policy calls: GPU only, and only with cached state embeddings (the window is then five small tensors)
+        self.use_graphs = (self.device.type == "cuda" and cache_state_embeddings) if use_graphs is None else \
+            (bool(use_graphs) and self.device.type == "cuda" and cache_state_embeddings)
+        self._graphs = {}
 
     # ---- context ---------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -92,11 +102,12 @@ class GreedyEvaluator:
 
     @torch.no_grad()
     def observe(self, ctx: PolicyContext, time, ob: torch.Tensor, rows: Optional[torch.Tensor] = None,
-                rtg: Optional[torch.Tensor] = None) -> None:
+                rtg: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None) -> None:
         """Write observation `ob` [n,16384] (and, if given, the return-to-go token `rtg` [n,1]) at step `time` (int, or a
         per-row int64 tensor) for `rows` (bool mask or None = all).  Masked writes are selects, not boolean-mask indexing:
         no `nonzero`, so no host synchronisation in the rollout loop."""
-        emb = self.model.encode_states(ob) if ctx.ee is not None else None
+        if emb is None:
+            emb = self.model.encode_states(ob) if ctx.ee is not None else None
         n = ob.shape[0]
         if isinstance(time, int):
             sel = None if rows is None else rows.reshape(n, 1)
@@ -113,6 +124,58 @@ class GreedyEvaluator:
             ctx.ee[idx, time] = emb if sel is None else torch.where(sel, emb, ctx.ee[idx, time])
         if rtg is not None:
             ctx.er[idx, time] = rtg if sel is None else torch.where(sel, rtg, ctx.er[idx, time])
+
+    # ---- hipGraph capture of the policy side ---------------------------------------------------------------
+    def _capture(self, fn):
+        """Warm `fn` up on a side stream (library handles, autotuning, allocator), then capture one call of it."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    @torch.no_grad()
+    def _graphed_encode(self, ob_src: torch.Tensor):
+        """`encode_states(policy_observation(x))` through a captured graph; x [n,1,H,W] float32 on the device."""
+        key = ("enc", tuple(ob_src.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            xs = torch.zeros_like(ob_src)
+            g, out = self._capture(lambda: (lambda ob: (ob, self.model.encode_states(ob)))(policy_observation(xs)))
+            ent = self._graphs[key] = (g, xs, out)
+        g, xs, out = ent
+        xs.copy_(ob_src)
+        g.replay()
+        return out                                          # (ob [n,16384], emb [n,E]): static tensors, consumed before the next replay
+
+    @torch.no_grad()
+    def _graphed_predict(self, ctx: PolicyContext, time: int):
+        """`_predict` for time >= ctx (window [time-ctx, time), action read at the last position, rtg at the second-to-last)."""
+        c = self.context_length
+        n = ctx.ea.shape[0]
+        key = ("predict", n)
+        ent = self._graphs.get(key)
+        if ent is None:
+            er, _, et, ek, ea, ee = (t.clone() if t is not None else None for t in ctx.window(0, c))
+
+            def body():
+                both, action_dict = self.model(er, ee, et, ek, ea, state_emb=ee)          # one forward, both heads (see _predict)
+                action = OrderedDict((k, v[:, -1, 0].contiguous()) for k, v in action_dict.items())
+                return action, both[:, -1, :self.action_dim].contiguous(), both[:, -2, self.action_dim:].contiguous()
+            g, out = self._capture(body)
+            ent = self._graphs[key] = (g, (er, et, ek, ea, ee), out)
+        g, (er, et, ek, ea, ee), (action, pa, rtg) = ent
+        lo, hi = time - c, time
+        er.copy_(ctx.er[:, lo:hi]); et.copy_(ctx.et[:, lo:hi]); ek.copy_(ctx.ek[:, lo:hi])
+        ea.copy_(ctx.ea[:, lo:hi]); ee.copy_(ctx.ee[:, lo:hi])
+        g.replay()
+        ctx.ea[:, time] = pa                                # outside the window (time >= ctx): the second forward did not need it
+        return OrderedDict((k, v.clone()) for k, v in action.items()), rtg.clone()
 
     # ---- policy calls --------------------------------------------------------------------------------------
     def _pick(self, action_dict, pred_actions, pos: int):
@@ -134,20 +197,32 @@ class GreedyEvaluator:
     @torch.no_grad()
     def _predict(self, ctx: PolicyContext, time: int):
         c = self.context_length
+        if self.use_graphs and time >= c and ctx.ee is not None:
+            return self._graphed_predict(ctx, time)
         lo, hi = (0, c) if time < c else (time - c, time)
         pa_pos = time if time < c else -1
         rtg_pos = time if time + 1 <= c else -2
         er, es, et, ek, ea, ee = ctx.window(lo, hi)
+        if time >= c:
+            # The reference's second forward (eval.py:176-184) sees the action it has just written at step `time` - which lies
+            # OUTSIDE the window [time-ctx, time): both forwards read identical tokens, so one forward with both heads gives
+            # the same action and return-to-go (the same tensors through the same kernels, bit for bit).
+            both, action_dict = self.model(er, es, et, ek, ea, state_emb=ee)
+            action, pa = self._pick(action_dict, both[..., :self.action_dim], pa_pos)
+            ctx.ea[:, time] = pa
+            return action, both[:, rtg_pos, self.action_dim:]
         pred_actions, action_dict = self.model(er, es, et, ek, ea, eval_actions=True, state_emb=ee)
         action, pa = self._pick(action_dict, pred_actions, pa_pos)
-        ctx.ea[:, time] = pa                                   # inside the window only while time < ctx (a view: `ea` sees it)
+        ctx.ea[:, time] = pa                                   # inside the window while time < ctx (a view: `ea` sees it)
         pred_rtg = self.model(er, es, et, ek, ea, eval_rtg=True, state_emb=ee)
         return action, pred_rtg[:, rtg_pos]
 
     @torch.no_grad()
-    def _predict_rows(self, ctx: PolicyContext, tvec: torch.Tensor):
+    def _predict_rows(self, ctx: PolicyContext, tvec: torch.Tensor, single_forward: bool = False):
         """`_predict` with a per-row time `tvec` [n] (int64, device): every row gets the window, read positions and write
-        position its own clock implies.  Rows whose clock has run past the last step are clamped (their result is unused)."""
+        position its own clock implies.  Rows whose clock has run past the last step are clamped (their result is unused).
+        single_forward: the caller knows every row that matters sits at time >= ctx, where the reference's two forwards read
+        identical tokens (see `_predict`): one forward, both heads."""
         c, T = self.context_length, self.max_timesteps
         n = tvec.shape[0]
         t = tvec.clamp(max=T - 1)
@@ -167,6 +242,11 @@ class GreedyEvaluator:
         ee = win(ctx.ee) if ctx.ee is not None else None
         es = win(ctx.es) if ctx.ee is None else ee              # with cached embeddings `states` is only read for its shape
         ea = win(ctx.ea)
+        if single_forward:
+            both, action_dict = self.model(er, es, et, ek, ea, state_emb=ee)
+            action = OrderedDict((k, v[rows, pos_a, 0].contiguous()) for k, v in action_dict.items())
+            ctx.ea[rows, t] = both[rows, pos_a, :self.action_dim]
+            return action, both[rows, pos_r, self.action_dim:]
         pred_actions, action_dict = self.model(er, es, et, ek, ea, eval_actions=True, state_emb=ee)
         action = OrderedDict((k, v[rows, pos_a, 0].contiguous()) for k, v in action_dict.items())
         pa = pred_actions[rows, pos_a]
@@ -193,7 +273,12 @@ class GreedyEvaluator:
             if (time - start_time) % self.sync_every == 0 and bool(stopped.all()):      # the loop's only host sync
                 break
             live = ~stopped
-            self.observe(ctx, time, policy_observation(states["x"]), live, rtg=pred_rtg)
+            x = states["x"]
+            if self.use_graphs and ctx.ee is not None and x.dim() == 4 and x.dtype == torch.float32:
+                ob, emb = self._graphed_encode(x)
+                self.observe(ctx, time, ob, live, rtg=pred_rtg, emb=emb)
+            else:
+                self.observe(ctx, time, policy_observation(x), live, rtg=pred_rtg)
             new_action, new_rtg = self._predict(ctx, time)
             for k in action:                                   # stopped slices keep the action that stopped them
                 action[k] = torch.where(live, new_action[k], action[k])
@@ -217,6 +302,9 @@ class GreedyEvaluator:
         stop_time = torch.full((n,), T, dtype=torch.int64, device=dev)
         one = torch.ones((), dtype=torch.float32, device=dev)
         steps = int(T + 1 - int(clock.min())) if n else 0
+        # earliest clock among the rows that take part (one host read, beside the one above): live rows advance by one per
+        # iteration, so from iteration ctx - first on every row that matters is past the warm-up window
+        first = int(torch.where(stopped, torch.full_like(clock, T + 1), clock).min()) if n else T + 1
         for it in range(max(steps, 0)):
             # rows that are out of the game are handed a stop action: the engine leaves them untouched (env.py:79-81)
             act = OrderedDict((k, (torch.where(stopped, one, v) if k == "T" else v)) for k, v in action.items())
@@ -229,7 +317,7 @@ class GreedyEvaluator:
                 break
             live = ~stopped
             self.observe(ctx, clock.clamp(max=T - 1), policy_observation(states["x"]), live, rtg=pred_rtg)
-            new_action, new_rtg = self._predict_rows(ctx, clock)
+            new_action, new_rtg = self._predict_rows(ctx, clock, single_forward=first + it >= self.context_length)
             for k in action:
                 action[k] = torch.where(live, new_action[k], action[k])
             pred_rtg = torch.where(live.reshape(n, 1), new_rtg, pred_rtg)

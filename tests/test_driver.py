@@ -383,3 +383,33 @@ def test_mcts_configs3_scale_batched_over_images():
     q, r1, s1 = search([0])
     assert s1["rounds"] == R and s1["rollouts"] >= 29
     assert abs(float(q[0]) - float(p1[0])) < 0.05
+
+
+@pytest.mark.gpu
+def test_graph_replayed_policy_equals_eager_policy():
+    """`use_graphs`: the steady-state policy calls (state encoder + the two transformer forwards) replayed from hipGraphs over
+    static window buffers are the same kernels on the same values as the eager calls: action sequences, stop times and final
+    PSNR of a 12-step rollout (6 eager steps, then replayed ones, one slice stopping on the way) are identical, bit for bit."""
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=12.0))
+    problem = synthetic.make_problem(3, 128, 128, accel=4.0, seed=21)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in problem.items()}
+    rtg = torch.full((3,), D.normalised_rtg(10.0))
+    task = torch.full((3,), 4)
+    res = {}
+    for graphs in (False, True):
+        ev = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), max_timesteps=12, device_type="cuda", sync_every=3, use_graphs=graphs)
+        assert ev.use_graphs == graphs
+        r1 = ev.run(mat, rtg, task)
+        r2 = ev.run(mat, rtg, task)                                  # second episode on the same evaluator: graphs are reused
+        assert torch.equal(r1.actions, r2.actions) and torch.equal(r1.reward, r2.reward)
+        res[graphs] = r1
+        if graphs:
+            assert {k[0] for k in ev._graphs} == {"enc", "predict"}
+    assert torch.equal(res[True].actions, res[False].actions)
+    assert torch.equal(res[True].stop_time, res[False].stop_time)
+    assert torch.equal(res[True].reward, res[False].reward)
+    assert torch.equal(res[True].x.cpu(), res[False].x.cpu())
