@@ -528,7 +528,12 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         st_tmp = W4T();
 #endif
         __syncthreads();                                   // chunk c is parked; the previous chunk's MFMA phase is done with V
-        if (UP2 && c >= nskip) { interpolate(); __syncthreads(); }
+        if (UP2 && c >= nskip) {
+            if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(3);
+            interpolate();
+            if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+        }
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_commit += t - st_tmp; st_tmp = t; }
 #endif
@@ -538,8 +543,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         // alone (~2 us) is shorter than an HBM round trip under load
         if constexpr (WN == 1) { if (c + 1 < nchunks) issue(c + 1); }
         __builtin_amdgcn_sched_barrier(0);                 // WN = 2: keep the next chunk's loads (20 registers) behind the transform
-        if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);
+        if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(3);   // two workgroups per CU: this one's few VALU instructions go
+        if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);   // ahead of the other's MFMA stream
         else wino4_input_transform<1, PW, CKQ, PLANE>(patch + win, V + vout);
+        if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         const frag_t* bp = bptr + (size_t)c * 36 * 64;
 #pragma unroll
