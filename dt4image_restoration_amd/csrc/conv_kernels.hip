@@ -600,26 +600,32 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ dst,
                                                          int N, int H, int W, int tilesX, int tilesY) {
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
-    __shared__ float dt[PH][PW + 1];
-    __shared__ float mt[PH][PW + 1];
+    constexpr int TYG = 8;                                     // tiles (of 8 rows) a workgroup walks down: the 76 weight / bias
+    __shared__ float dt[2][PH][PW + 1];                        // registers of a thread are loaded once per 64 rows, and the next
+    __shared__ float mt[2][PH][PW + 1];                        // tile's halo is staged (double buffer) under this tile's FMAs
+    const int groupsY = (tilesY + TYG - 1) / TYG;
     int bt = blockIdx.x;
     const int tx0 = (bt % tilesX) * TW;
     bt /= tilesX;
-    const int ty0 = (bt % tilesY) * TH;
-    const int n = bt / tilesY;
+    const int tyg = bt % groupsY;
+    const int n = bt / groupsY;
     if (tact != nullptr && tact[n] > 0.5f) return;
-    for (int i = threadIdx.x; i < PH * PW; i += 256) {
-        const int py = i / PW, px = i % PW;
-        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-        float d = 0.f, m = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const size_t q = ((size_t)n * H + gy) * W + gx;
-            d = ximg != nullptr ? ximg[q] : (z[q].x - u[q].x);
-            m = 1.f;
+    auto stage = [&](int buf, int ty0) {
+        for (int i = threadIdx.x; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i % PW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            float d = 0.f, m = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t q = ((size_t)n * H + gy) * W + gx;
+                d = ximg != nullptr ? ximg[q] : (z[q].x - u[q].x);
+                m = 1.f;
+            }
+            dt[buf][py][px] = d;
+            mt[buf][py][px] = m;
         }
-        dt[py][px] = d;
-        mt[py][px] = m;
-    }
+    };
+    const int t_first = tyg * TYG, t_last = min(t_first + TYG, tilesY);
+    stage(0, t_first * TH);
     const int cg = threadIdx.x & 7, col = threadIdx.x >> 3;
     float wd[4][9], ws[4][9], br[4];
     const float sg = sigma[n];
@@ -632,38 +638,42 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
             ws[j][k] = w[(cg * 4 + j) * 18 + 9 + k] * sg;      // sigma folded into the second channel's taps
         }
     }
-    __syncthreads();
-    float d[3][3], m[3][3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { d[r + 1][c] = dt[r][col + c]; m[r + 1][c] = mt[r][col + c]; }
     const int gx = tx0 + col;
+    for (int t = t_first; t < t_last; ++t) {
+        const int buf = (t - t_first) & 1, ty0 = t * TH;
+        __syncthreads();                                       // this tile's halo is staged; the other buffer is free again
+        if (t + 1 < t_last) stage(buf ^ 1, ty0 + TH);
+        float d[3][3], m[3][3];
 #pragma unroll
-    for (int row = 0; row < TH; ++row) {
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {                          // slide the window one row down
-            d[0][c] = d[1][c]; d[1][c] = d[2][c]; d[2][c] = dt[row + 2][col + c];
-            m[0][c] = m[1][c]; m[1][c] = m[2][c]; m[2][c] = mt[row + 2][col + c];
-        }
-        float acc[4] = {br[0], br[1], br[2], br[3]};
+            for (int c = 0; c < 3; ++c) { d[r + 1][c] = dt[buf][r][col + c]; m[r + 1][c] = mt[buf][r][col + c]; }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int row = 0; row < TH; ++row) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int c = 0; c < 3; ++c) {                      // slide the window one row down
+                d[0][c] = d[1][c]; d[1][c] = d[2][c]; d[2][c] = dt[buf][row + 2][col + c];
+                m[0][c] = m[1][c]; m[1][c] = m[2][c]; m[2][c] = mt[buf][row + 2][col + c];
+            }
+            float acc[4] = {br[0], br[1], br[2], br[3]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j] = fmaf(wd[j][ky * 3 + kx], d[ky][kx], acc[j]);
-                    acc[j] = fmaf(ws[j][ky * 3 + kx], m[ky][kx], acc[j]);
-                }
-        const int gy = ty0 + row;
-        if (gy < H && gx < W) {
-            float4 o;
-            o.x = fmaxf(acc[0], kLeaky * acc[0]);
-            o.y = fmaxf(acc[1], kLeaky * acc[1]);
-            o.z = fmaxf(acc[2], kLeaky * acc[2]);
-            o.w = fmaxf(acc[3], kLeaky * acc[3]);
-            *reinterpret_cast<float4*>(dst + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o;
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = fmaf(wd[j][ky * 3 + kx], d[ky][kx], acc[j]);
+                        acc[j] = fmaf(ws[j][ky * 3 + kx], m[ky][kx], acc[j]);
+                    }
+            const int gy = ty0 + row;
+            if (gy < H && gx < W) {
+                float4 o;
+                o.x = fmaxf(acc[0], kLeaky * acc[0]);
+                o.y = fmaxf(acc[1], kLeaky * acc[1]);
+                o.z = fmaxf(acc[2], kLeaky * acc[2]);
+                o.w = fmaxf(acc[3], kLeaky * acc[3]);
+                *reinterpret_cast<float4*>(dst + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o;
+            }
         }
     }
 }
@@ -671,8 +681,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
                              const float* tact, const float* w, const float* bias, float* dst, int N, int H, int W,
                              hipStream_t s) {
-    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tilesX * tilesY * N)), dim3(256), 0, s, ximg, z, u, sigma, tact, w,
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8, groupsY = (tilesY + 7) / 8;
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tilesX * groupsY * N)), dim3(256), 0, s, ximg, z, u, sigma, tact, w,
                        bias, dst, N, H, W, tilesX, tilesY);
     return hipGetLastError();
 }
