@@ -89,6 +89,7 @@ struct pnp_engine {
     ConvPlan cplan[N_LAYERS] = {};    // the same plan
     bool wino[N_LAYERS] = {};         // layer runs on the Winograd kernel (weights packed for it)
     bool fuse_last = false;           // last 1x1 layer rides in the epilogue of up4.conv-2
+    bool fuse_first = false;          // first layer (2 -> 32) is computed in the staging of inc.conv-1 (F(4x4) 32-channel variant)
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
     // data-fidelity stage
     FftPlan plan = {};
@@ -158,7 +159,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
     const int N = e->cfg.n, H = e->cfg.h, W = e->cfg.w;
     if (e->cfg.flags & PNP_FLAG_NO_DENOISER)
         return fail(PNP_ERR_STATE, "this handle was created with PNP_FLAG_NO_DENOISER");
-    {
+    if (!e->fuse_first) {
         Prof p(e, s, 1, 0);
         HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
     }
@@ -178,7 +179,12 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
             a.rh = a.H > 1 ? (float)(hs - 1) / (float)(a.H - 1) : 0.f;
             a.rw = a.W > 1 ? (float)(ws - 1) / (float)(a.W - 1) : 0.f;
         }
-        const int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
+        int src_mode = (L.src == SRC_POOL && src_is_pooled) ? (int)SRC_PLAIN : L.src;   // pooled copy already exists
+        if (li == 1 && e->fuse_first) {                    // inc.conv-1 evaluates the first layer while staging its patch
+            src_mode = SRC_FIRST;
+            a.first_w = e->d_wpack[0]; a.first_b = e->d_bias[0]; a.first_sigma = sigma;
+            a.last_ximg = ximg; a.last_z = z; a.last_u = u;
+        }
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;
         if (e->wino[li] && e->wplan[li].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[li], src_mode, s));
@@ -324,6 +330,7 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cplan[li]));
         }
         e->fuse_last = !(cfg->flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cplan[26]));
+        e->fuse_first = e->wino[1] && e->wplan[1].algo == 4 && e->wplan[1].bn == 32 && e->wplan[1].mt == 32 && !e->tune.no_f4_fused_first;
     }
     const size_t cbytes = N * H * W * sizeof(float2);
     if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||

@@ -18,6 +18,7 @@ struct Tuning {
     bool no_wino = false;         // PNP_NO_WINOGRAD
     int f4_min_cin = 32;          // PNP_WINO_F4_MIN_CIN: F(4x4,3x3) for layers with at least this many input channels
     bool no_f4 = false;           // PNP_NO_WINO_F4
+    bool no_f4_fused_first = false;// PNP_NO_F4_FUSED_FIRST: the first layer as its own kernel (conv_first_kernel)
     bool no_f4_fused_last = false;// PNP_NO_F4_FUSED_LAST: up4.conv-2 (+ fused last layer) on the F(2x2) kernel
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
     int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
@@ -34,7 +35,7 @@ struct DeviceOnce { std::atomic<uint64_t> mask{0}; };
 hipError_t raise_lds_cap(const void* fn, int bytes, DeviceOnce& once);
 
 // ---- denoiser conv layer description (mirrors dt4image_restoration_amd/unet_spec.py) ----------
-enum SrcMode : int { SRC_PLAIN = 0, SRC_SIGMA = 1, SRC_POOL = 2, SRC_UPCAT = 3 };
+enum SrcMode : int { SRC_PLAIN = 0, SRC_SIGMA = 1, SRC_POOL = 2, SRC_UPCAT = 3, SRC_FIRST = 4 };   // FIRST: F(4x4) 32-channel variant only
 
 struct LayerSpec {
     int cin, cout, ksize, level, src, cskip;
@@ -52,6 +53,9 @@ struct ConvArgs {
     float* pooled;       // optional: also write MaxPool2d(2) of the output, [N,H/2,W/2,Cout] (H, W even)
     // optional fused last layer (1x1 conv 32 -> 1 + image residual + clamp), Cout = 32 LDS-epilogue plan only:
     const float* last_w; const float* last_b; const float* last_ximg; const float2* last_z; const float2* last_u; float* last_out;
+    // optional fused FIRST layer (SRC_FIRST: sigma-plane cat + conv 2 -> 32 + LeakyReLU computed into the patch; the image channel comes
+    // from last_ximg or Re(last_z - last_u)): raw [32][18] weights, [32] bias, [N] sigma
+    const float* first_w; const float* first_b; const float* first_sigma;
     float* partial;      // split-K workspace, conv3x3_partial_floats() floats (small problems only)
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     static_assert(MT == 32 || (MT == 16 && WN == 2), "16-tile M-blocks: 64-channel workgroups only");
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr bool UP2 = SRC == SRC_UPCAT;
+    constexpr bool FIRST = SRC == SRC_FIRST;           // the patch is the denoiser's FIRST layer, computed here (see first_patch)
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
     constexpr int LITEMS = LH * LW * PPP;
     constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     constexpr int KEEP = 3;                            // ... of which only the first KEEP are loaded across the chunk boundary (the
                                                        // input transform needs the registers); the rest go out after the transform
     constexpr int PLANE = MT * CKP;                    // floats per frequency plane of V
-    static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT, "pooled sources go through the pooled copy");
+    static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT || SRC == SRC_FIRST, "pooled sources go through the pooled copy");
+    static_assert(!FIRST || (WN == 1 && MT == 32), "fused first layer: the 32-channel variant");
     static_assert(36 % PF == 0 && MT * HCN * 2 == NT_, "one (tile, 2-channel, column group) transform item per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -339,6 +341,13 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][LP] low-res source region of the chunk being staged
     float* const rowT = lowres + LH * LW * LP;             // UPCAT: per patch row / column {offset of the two source lines in the
     float* const colT = rowT + 4 * PH;                     // low-res region (int), their two weights}; zeros outside the image
+    // FIRST: image halo tile (2 pixels around the patch... 1 around each patch pixel's 3x3 window), its in-image mask, and the
+    // first layer's weights [18 taps][32 channels] (sigma taps pre-scaled by sigma), bias, and the sigma taps' per-channel sum
+    constexpr int IW = PW + 3;                             // row stride of the image tile (PW + 2 used)
+    float* const dimg = V + 36 * PLANE;                    // [PH + 2][IW]
+    float* const mimg = dimg + (PH + 2) * IW;
+    float* const wl = mimg + (PH + 2) * IW;                // [18][32]
+    float* const bl = wl + 18 * 32;                        // [32] bias, [32] bias + sigma-plane constant (interior pixels)
 #ifdef PNP_STAMPS
     unsigned long long st_t0 = W4T(), st_setup = 0, st_loop0 = 0, st_commit = 0, st_trans = 0, st_mfma = 0, st_loop1 = 0, st_ew = 0, st_er = 0, st_tmp = 0;
 #endif
@@ -468,6 +477,80 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             }
         }
     };
+    // ---- FIRST: the denoiser's first layer (sigma-plane cat + conv 2 -> 32 + LeakyReLU, noise.py:157-162,104; conv_first_kernel)
+    // evaluated for the patch pixels of chunk c's 8 channels straight into the patch: its 537 MB output is neither written nor
+    // read back (that layer is bound by its stores, this one by its loads).  Thread item = (patch pixel, 4 channels); taps outer,
+    // items inner: one weight vector and NIT x 4 accumulators live.  Workgroups whose patch windows lie inside the image fold the
+    // sigma plane (= 1 everywhere) into the bias; border workgroups add its taps under the in-image mask.  Pixels outside the
+    // image are this conv's zero padding.
+    bool first_interior = false;
+    int fbase[FIRST ? NIT : 1];
+    if constexpr (FIRST) {
+        first_interior = ty0 >= 2 && ty0 + TH + 2 <= a.H && tx0 >= 2 && tx0 + TW + 2 <= a.W;
+        const float sg = a.first_sigma[n];
+        for (int i = tid; i < (PH + 2) * (PW + 2); i += NT_) {
+            const int r = i / (PW + 2), q = i % (PW + 2);
+            const int gy = ty0 - 2 + r, gx = tx0 - 2 + q;
+            float d = 0.f, m = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t qx = ((size_t)n * a.H + gy) * a.W + gx;
+                d = a.last_ximg != nullptr ? a.last_ximg[qx] : (a.last_z[qx].x - a.last_u[qx].x);
+                m = 1.f;
+            }
+            dimg[r * IW + q] = d;
+            mimg[r * IW + q] = m;
+        }
+        for (int i = tid; i < 32 * 18; i += NT_) {
+            const int ch = i / 18, t = i % 18;
+            wl[t * 32 + ch] = a.first_w[i] * (t >= 9 ? sg : 1.f);
+        }
+        if (tid < 32) {
+            float sc = 0.f;
+#pragma unroll
+            for (int t = 9; t < 18; ++t) sc += a.first_w[tid * 18 + t] * sg;
+            bl[tid] = a.first_b[tid];
+            bl[32 + tid] = a.first_b[tid] + sc;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int pp = (tid + k * NT_) / PPP;
+            fbase[k] = (tid + k * NT_ < ITEMS) ? (pp / PW) * IW + pp % PW : 0;
+        }
+        __syncthreads();
+    }
+    auto first_patch = [&](int c) {
+        if constexpr (FIRST) {
+            const int part = tid % PPP;                    // (NT_ is a multiple of PPP: the same part for all of a thread's items)
+            const float* const wq = wl + CK * c + 4 * part;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + (first_interior ? 32 : 0) + CK * c + 4 * part);
+            f32x4 acc[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) acc[k] = b4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wq + t * 32);
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) acc[k] = __builtin_elementwise_fma(w4, f32x4(dimg[fbase[k] + (t / 3) * IW + t % 3]), acc[k]);
+            }
+            if (!first_interior) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wq + (9 + t) * 32);
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) acc[k] = __builtin_elementwise_fma(w4, f32x4(mimg[fbase[k] + (t / 3) * IW + t % 3]), acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * NT_;
+                if (idx < ITEMS) {
+                    const float in = first_interior ? 1.f : mimg[fbase[k] + IW + 1];      // the patch pixel itself inside the image?
+                    const f32x4 v = in * __builtin_elementwise_max(acc[k], kLeaky * acc[k]);
+                    put_patch((idx / PPP) * CKQ + part * 4, make_float4(v[0], v[1], v[2], v[3]));
+                }
+            }
+        }
+    };
     if constexpr (UP2) {
         // the interpolation's coordinates are the same for every chunk: one table entry per patch row and column, built once
         // (first read behind the loop-top barrier).  Pixels outside the image (the conv's zero padding) get zero weights.
@@ -487,8 +570,8 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             *reinterpret_cast<float4*>(&(isrow ? rowT : colT)[4 * pq]) = e;
         }
     }
-    issue(0);
-    park(0);
+    if constexpr (FIRST) first_patch(0);
+    else { issue(0); park(0); }
 
     // this thread's transform item: tile tq of the workgroup's 32 tiles (TC per row), channels [2*hc, 2*hc+2), frequency
     // column group tj (first half of the waves: columns 0..2, second half: columns 3..5; all six rows).  HCN lanes cover a
@@ -541,7 +624,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         // ---- input transform V = B^T d B: all six frequency rows of this thread's column group ------------------------------
         // WN = 1 (32 -> 32 layers: 4 short chunks): the next chunk's loads go out BEFORE the transform - a chunk's MFMA phase
         // alone (~2 us) is shorter than an HBM round trip under load
-        if constexpr (WN == 1) { if (c + 1 < nchunks) issue(c + 1); }
+        if constexpr (WN == 1 && !FIRST) { if (c + 1 < nchunks) issue(c + 1); }
         __builtin_amdgcn_sched_barrier(0);                 // WN = 2: keep the next chunk's loads (20 registers) behind the transform
         if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(3);   // two workgroups per CU: this one's few VALU instructions go
         if (tj == 0) wino4_input_transform<0, PW, CKQ, PLANE>(patch + win, V + vout);   // ahead of the other's MFMA stream
@@ -580,7 +663,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_mfma += t - st_tmp; }
 #endif
-        if (c + 1 < nchunks) park(c + 1);
+        if (c + 1 < nchunks) {
+            if constexpr (FIRST) first_patch(c + 1);
+            else park(c + 1);
+        }
     }
 #ifdef PNP_STAMPS
     st_loop1 = W4T();
@@ -814,7 +900,8 @@ static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStr
     constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = MT / TC, TH = 4 * TR;
     constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
     constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) + 4 * (TH + 2 + TW + 2) : 0;   // + tables
-    constexpr size_t lds = (patch_f + (size_t)36 * MT * CKP + lowres_f) * sizeof(float);
+    constexpr size_t first_f = SRC == SRC_FIRST ? (size_t)2 * (TH + 4) * (TW + 5) + 18 * 32 + 64 : 0;   // image tile + mask, weights, bias
+    constexpr size_t lds = (patch_f + (size_t)36 * MT * CKP + lowres_f + first_f) * sizeof(float);
     static_assert(lds <= (WN == 2 && MT == 32 ? 160 : 80) * 1024, "one (8 waves) / two (4 waves) workgroups per CU");
     if (p.th != TH || p.tw != TW) return hipErrorInvalidValue;
     auto kern = conv3x3_wino4_kernel<TW, SRC, STK, WN, MT>;
@@ -840,6 +927,8 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
         if (p.ck != 8 || p.stack) return hipErrorInvalidValue;
         if (p.tw == 32 && src_mode == SRC_PLAIN) return launch_wino4_inst<32, SRC_PLAIN, false, 1>(a, p, s);
         if (p.tw == 32 && src_mode == SRC_UPCAT) return launch_wino4_inst<32, SRC_UPCAT, false, 1>(a, p, s);
+        if (p.tw == 32 && src_mode == SRC_FIRST) return launch_wino4_inst<32, SRC_FIRST, false, 1>(a, p, s);
+        if (p.tw == 16 && src_mode == SRC_FIRST) return launch_wino4_inst<16, SRC_FIRST, false, 1>(a, p, s);
         if (p.tw == 16 && src_mode == SRC_PLAIN) return launch_wino4_inst<16, SRC_PLAIN, false, 1>(a, p, s);
         if (p.tw == 16 && src_mode == SRC_UPCAT) return launch_wino4_inst<16, SRC_UPCAT, false, 1>(a, p, s);
         return hipErrorInvalidValue;
