@@ -1,4 +1,6 @@
-// Winograd F(4x4, 3x3) convolution for the denoiser layers with Cin >= 32 (25 of the 26 conv3x3 layers) on gfx950 (MI355X).
+// Winograd F(4x4, 3x3) convolution for the denoiser layers with Cin >= 32 (all 26 conv3x3 layers at the headline size) on gfx950
+// (MI355X); the first of them also evaluates the 2 -> 32 input layer in its staging (SRC_FIRST), the last carries the 1x1 output
+// layer in its epilogue.
 //
 // Same operator as conv3x3_winograd_kernel / conv3x3_mfma_kernel (conv3x3 s1 p1 + bias + LeakyReLU(0.2),
 // /root/reference/evaluation/noise.py:75-98, the stage's bilinear-upsample+concat input transform applied while staging),
