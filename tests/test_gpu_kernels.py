@@ -334,3 +334,25 @@ def test_slice128_single_workgroup_stage_matches_three_launch_path_and_oracle(mo
     uo = u0 + xr - zo
     live = [0, 1, 3, 4]
     assert float((z1[live] - zo[live]).abs().max()) < 3e-6 and float((u1[live] - uo[live]).abs().max()) < 3e-6
+
+
+def test_fused_first_and_last_layer_match_their_own_kernels(sd_np, monkeypatch):
+    """At the headline size the first layer (2 -> 32) is evaluated inside inc.conv-1's staging and the last one (1x1, residual, clamp)
+    inside up4.conv-2's epilogue; `PNP_NO_F4_FUSED_FIRST` / `PNP_NO_F4_FUSED_LAST` put them back on their own kernels.  Same
+    arithmetic up to the order of a few additions: the denoiser output agrees to 2e-6, and both agree with the oracle."""
+    n, h, w = 3, 256, 256
+    x = (torch.from_numpy(synthetic.hash_uniform(23, 7, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
+    sigma = torch.linspace(4, 40, n) / 255.0
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("PNP_NO_F4_FUSED_FIRST", "1")
+            monkeypatch.setenv("PNP_NO_F4_FUSED_LAST", "1")
+        e = _engine(n, h, w, sd_np)
+        algos = e.conv_algorithms()
+        assert algos[1] == 4 and algos[26] == (4 if fused else 1), algos   # inc.conv-1 / up4.conv-2: the layers that carry the fusions
+        outs[fused] = e.denoise(x.cuda(), sigma.cuda()).cpu()
+    # FLOAT TOLERANCE: f32, different summation order in two layers
+    np.testing.assert_allclose(outs[True].numpy(), outs[False].numpy(), rtol=0, atol=2e-6)
+    ref = O.denoise(O.torch_weights(sd_np), x, sigma)
+    np.testing.assert_allclose(outs[True].numpy(), ref.numpy(), rtol=0, atol=1e-5)
