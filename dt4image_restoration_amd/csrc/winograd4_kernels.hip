@@ -310,7 +310,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
 // lockstep between them (the upsample + concat layers; 16 x 16 images need no stacking: 4 x 4 tiles are one slice).
 template <int TW, int SRC, bool STK = false, int WN = 2, int MT = 32>
 __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const ConvArgs a) {
-    constexpr int CK = 8 * WN, CKP = CK, LP = CK + 4, PPP = CK / 4, NT_ = 8 * MT * WN;   // CKP / LP: pixel stride of V / the low-res region
+    constexpr int CK = 8 * WN, CKP = CK, LP = CK, PPP = CK / 4, NT_ = 8 * MT * WN;   // CKP / LP: pixel stride of V / the low-res region (no
+                                                       // padding: neighbouring output pixels interpolate from the same source pixels - broadcasts)
     constexpr int CKQ = WN == 2 ? CK + 4 : CK + 2;     // patch pixel stride (floats): b64 window reads conflict-free for both
     constexpr int HCN = CK / 2;                        // 2-channel units per pixel
     constexpr int TC = TW / 4, TR = MT / TC;           // tiles per row / rows of tiles in the MT-tile M-block
@@ -901,7 +902,7 @@ template <int TW, int SRC, bool STK = false, int WN = 2, int MT = 32>
 static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStream_t s) {
     constexpr int CK = 8 * WN, CKP = CK, CKQ = WN == 2 ? CK + 4 : CK + 2, TC = TW / 4, TR = MT / TC, TH = 4 * TR;
     constexpr size_t patch_f = (((size_t)(STK ? TH + 4 : TH + 2) * (TW + 2) * CKQ + 3) / 4) * 4;
-    constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * (CK + 4) + 4 * (TH + 2 + TW + 2) : 0;   // + tables
+    constexpr size_t lowres_f = SRC == SRC_UPCAT ? (size_t)(TH / 2 + 3) * (TW / 2 + 3) * CK + 4 * (TH + 2 + TW + 2) : 0;   // + tables
     constexpr size_t first_f = SRC == SRC_FIRST ? (size_t)2 * (TH + 4) * (TW + 5) + 18 * 32 + 64 : 0;   // image tile + mask, weights, bias
     constexpr size_t lds = (patch_f + (size_t)36 * MT * CKP + lowres_f + first_f) * sizeof(float);
     static_assert(lds <= (WN == 2 && MT == 32 ? 160 : 80) * 1024, "one (8 waves) / two (4 waves) workgroups per CU");
