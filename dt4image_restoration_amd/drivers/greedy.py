@@ -127,7 +127,19 @@ class GreedyEvaluator:
 
     # ---- hipGraph capture of the policy side ---------------------------------------------------------------
     def _capture(self, fn):
-        """Warm `fn` up on a side stream (library handles, autotuning, allocator), then capture one call of it."""
+        """Warm `fn` up on a side stream (library handles, autotuning, allocator), then capture one call of it.  A capture
+        that fails (a PyTorch build or op that cannot be captured) switches the evaluator back to eager policy calls - the same
+        kernels launched one by one - with a warning; the HIP env is not involved either way."""
+        try:
+            return self._capture_unguarded(fn)
+        except Exception as exc:                                # noqa: BLE001 - any capture failure means "run eager"
+            import warnings
+            warnings.warn(f"hipGraph capture of the policy failed ({type(exc).__name__}: {exc}); continuing with eager policy calls")
+            self.use_graphs = False
+            torch.cuda.synchronize(self.device)
+            return None, None
+
+    def _capture_unguarded(self, fn):
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -147,6 +159,9 @@ class GreedyEvaluator:
         if ent is None:
             xs = torch.zeros_like(ob_src)
             g, out = self._capture(lambda: (lambda ob: (ob, self.model.encode_states(ob)))(policy_observation(xs)))
+            if g is None:
+                ob = policy_observation(ob_src)
+                return ob, self.model.encode_states(ob)
             ent = self._graphs[key] = (g, xs, out)
         g, xs, out = ent
         xs.copy_(ob_src)
@@ -168,6 +183,8 @@ class GreedyEvaluator:
                 action = OrderedDict((k, v[:, -1, 0].contiguous()) for k, v in action_dict.items())
                 return action, both[:, -1, :self.action_dim].contiguous(), both[:, -2, self.action_dim:].contiguous()
             g, out = self._capture(body)
+            if g is None:
+                return self._predict(ctx, time)                # use_graphs is off now: the eager path
             ent = self._graphs[key] = (g, (er, et, ek, ea, ee), out)
         g, (er, et, ek, ea, ee), (action, pa, rtg) = ent
         lo, hi = time - c, time
