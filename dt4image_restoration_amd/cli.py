@@ -5,8 +5,8 @@
     python -m dt4image_restoration_amd.cli --block_size 18 --n_embeds 6 flex --max_timesteps 30
 
 Multi-GPU (BASELINE configs[2]): launch the same command under `python -m torch.distributed.run --nproc-per-node N
---master-addr 127.0.0.1 -m dt4image_restoration_amd.cli ... eval ...`: every rank takes a contiguous shard of each set's
-images (drivers/sharded.py), the per-image PSNR / stop iteration are gathered over RCCL, rank 0 prints.
+--master-addr 127.0.0.1 -m dt4image_restoration_amd.cli ... eval|mcts|flex ...`: every rank takes a contiguous shard of each
+set's images (drivers/sharded.py), the per-image PSNR / stop iteration are gathered over RCCL, rank 0 prints.
 
 Differences: `train` is out of scope; checkpoint and data locations are options instead of
 hard-coded paths (main.py:175,178,181-183); without `--data` the run uses the seeded synthetic problems and without
@@ -57,12 +57,6 @@ def _sets(args, flex_target=None):
             yield f"synthetic {accel}x_{sig}", args.limit or 7, load
 
 
-def _batches(args, flex_target=None):
-    for name, total, load in _sets(args, flex_target):
-        batch, tokens = load(0, total)
-        yield name, batch, tokens
-
-
 def main(argv=None):
     ap = argparse.ArgumentParser(description="PnP-ADMM CS-MRI restoration with a decision-transformer policy (MI355X)")
     ap.add_argument("--block_size", type=int, required=True)
@@ -94,8 +88,6 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        if args.mode == "flex":
-            raise SystemExit("multi-GPU launch is implemented for `eval` and `mcts` (slices / images shard over the ranks)")
     if args.mode == "eval":
         model, env, _ = _build(args, "norm")
         ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size,
@@ -135,18 +127,25 @@ def main(argv=None):
             dist.destroy_process_group()
         return out
     if True:
+        # main.py:187-209: the greedy evaluation once per return-to-go target, PSNR increment averaged over the sets; sharded over
+        # the ranks like `eval` (every rank a contiguous shard of each set, one gather per set)
         model, env, _ = _build(args, "flex")
-        ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size)
+        ev = GreedyEvaluator(model, env, max_timesteps=args.max_timesteps, block_size=args.block_size,
+                             device_type=torch.device("cuda", torch.cuda.current_device()))
         for target in (1.5, 3, 3.5, 4, 4.5):                       # main.py:198
             incs = []
-            for name, batch, tokens in _batches(args, flex_target=target):
-                mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
-                n = mat["gt"].shape[0]
-                r = ev.run(mat, torch.full((n,), D.normalised_rtg(target, flex=True)), torch.from_numpy(tokens),
-                           first_state=mat.get("x0_raw"))
+            for name, total, load in _sets(args, flex_target=target):
+                def load_shard(a, b, load=load):
+                    batch, tokens = load(a, b)
+                    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
+                    return mat, torch.full((b - a,), D.normalised_rtg(target, flex=True)), torch.from_numpy(tokens)
+                r = run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize)
                 incs.append(float((r.reward - r.initial_reward).mean()))
-            out.append({"rtg_target": target, "average_increment": float(np.mean(incs))})
-            print(json.dumps(out[-1]), flush=True)
+            out.append({"rtg_target": target, "average_increment": float(np.mean(incs)), "ranks": world})
+            if rank == 0:
+                print(json.dumps(out[-1]), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
     return out
 
 

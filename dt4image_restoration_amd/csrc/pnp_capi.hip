@@ -270,6 +270,15 @@ extern "C" {
 const char* pnp_last_error(void) { return g_err.c_str(); }
 const char* pnp_version(void) { return "pnpadmm 0.3 (gfx950, f32 MFMA; optional bf16-operand convs)"; }
 
+// Does layer `li` (a stage's last conv, planned already) also write the 2x2 max-pooled copy of its output?  Its output must have
+// even sides and its kernel must support it (a Winograd kernel, or the direct kernel's LDS-epilogue plan).  ONE predicate for the
+// consumer's planned source mode and for the launch-time pool_ok[] flags.
+static bool pooled_copy_ok(const pnp_engine* e, int li) {
+    const LayerSpec& L = kLayers[li];
+    const int lh = e->cfg.h >> L.level, lw = e->cfg.w >> L.level;
+    return lh % 2 == 0 && lw % 2 == 0 && (e->wino[li] || conv3x3_pooled_output_ok(e->cplan[li]));
+}
+
 static int create_impl(const pnp_config* cfg, pnp_engine* e) {
     e->cfg = *cfg;
     e->tune = tuning_from_env();
@@ -298,9 +307,10 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             const int lh = cfg->h >> L.level, lw = cfg->w >> L.level;
             // the source mode the launch will use: a pooled stage input is read PLAIN from the producer's pooled copy, which
             // exists iff the producing layer (li - 1, planned just before) runs a Winograd kernel or the direct LDS-epilogue plan
+            // (the same predicate as pool_ok[] below: the producer's output size - twice this layer's - must be even, which it
+            // always is, and its kernel must be one that writes the pooled copy)
             int src_mode = L.src;
-            if (L.src == SRC_POOL && (lh * 2) % 2 == 0 && (e->wino[li - 1] || conv3x3_pooled_output_ok(e->cplan[li - 1])))
-                src_mode = SRC_PLAIN;
+            if (L.src == SRC_POOL && pooled_copy_ok(e, li - 1)) src_mode = SRC_PLAIN;
             e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, e->tune);
             if (li == 26 && e->wplan[li].algo == 4 && !(cfg->flags & PNP_FLAG_KEEP_STAGES) &&
                 (e->tune.no_f4_fused_last || e->wplan[li].bn != 32 || e->wplan[li].mt != 32)) {
@@ -327,7 +337,8 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             const int li = 3 * k + 2;
             const LayerSpec& L = kLayers[li];
             const int lh = cfg->h >> L.level, lw = cfg->w >> L.level;
-            e->pool_ok[k] = (lh % 2 == 0 && lw % 2 == 0) && (e->wino[li] || conv3x3_pooled_output_ok(e->cplan[li]));
+            (void)lh; (void)lw;
+            e->pool_ok[k] = pooled_copy_ok(e, li);
         }
         e->fuse_last = !(cfg->flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cplan[26]));
         e->fuse_first = e->wino[1] && e->wplan[1].algo == 4 && e->wplan[1].bn == 32 && e->wplan[1].mt == 32 && !e->tune.no_f4_fused_first;

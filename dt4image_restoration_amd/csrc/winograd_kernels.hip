@@ -89,21 +89,23 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
         f.tiles_x = (W + f.tw - 1) / f.tw;
         f.tiles_y = (H + f.th - 1) / f.th;
         f.stack = (W == 16 && H == 16) ? 1 : 0;             // 16 x 16 images: two slices per 32-tile workgroup
-        if (f.stack && Cout == 32) return p;
-        f.mt = 32;
-        // 16-tile M-blocks (two independent workgroups per CU): measured faster than the lockstep schedules on the upsample + concat
-        // layers (-2..3.5 %) and on the short-K plain layers (Cin <= 64: -3..5 %), equal at 128, slower from 256 channels on
-        const bool mt16 = t.f4_mt16 == 0 ? (src_mode == SRC_UPCAT || Cin <= 64) : (t.f4_mt16 == 1 ? false : (t.f4_mt16 == 2 ? src_mode == SRC_UPCAT : true));
-        if (f.bn == 64 && mt16 && (f.tw == 32 ? H >= 8 : H >= 16)) {
-            f.mt = 16;                                      // 8 x 32 or 16 x 16 pixels per workgroup
-            f.th = f.tw == 32 ? 8 : 16;
-            f.tiles_y = (H + f.th - 1) / f.th;
-            f.stack = 0;
+        // (stacked 16 x 16 slices have no 32-channel variant: such a layer skips F(4x4) only and is planned as F(2x2) below)
+        if (!(f.stack && Cout == 32)) {
+            f.mt = 32;
+            // 16-tile M-blocks (two independent workgroups per CU): measured faster than the lockstep schedules on the upsample + concat
+            // layers (-2..3.5 %) and on the short-K plain layers (Cin <= 64: -3..5 %), equal at 128, slower from 256 channels on
+            const bool mt16 = t.f4_mt16 == 0 ? (src_mode == SRC_UPCAT || Cin <= 64) : (t.f4_mt16 == 1 ? false : (t.f4_mt16 == 2 ? src_mode == SRC_UPCAT : true));
+            if (f.bn == 64 && mt16 && (f.tw == 32 ? H >= 8 : H >= 16)) {
+                f.mt = 16;                                      // 8 x 32 or 16 x 16 pixels per workgroup
+                f.th = f.tw == 32 ? 8 : 16;
+                f.tiles_y = (H + f.th - 1) / f.th;
+                f.stack = 0;
+            }
+            f.phased = (f.mt == 32 && f.bn == 64 && src_mode == SRC_PLAIN && !t.no_f4_phased) ? 1 : 0;
+            const long blocks = (long)f.tiles_x * f.tiles_y * (f.stack ? (N + 1) / 2 : N) * (Cout / f.bn);
+            f.use = blocks >= t.wino_min_blocks;
+            if (f.use) return f;
         }
-        f.phased = (f.mt == 32 && f.bn == 64 && src_mode == SRC_PLAIN && !t.no_f4_phased) ? 1 : 0;
-        const long blocks = (long)f.tiles_x * f.tiles_y * (f.stack ? (N + 1) / 2 : N) * (Cout / f.bn);
-        f.use = blocks >= t.wino_min_blocks;
-        if (f.use) return f;
     }
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     // Cout >= 128: one 8-wave workgroup per CU (32 tiles x 128 channels, 32-channel chunks).  Cout = 64 / 32: 4-wave

@@ -19,10 +19,11 @@ encoder is a pure per-image function, so each observation is encoded ONCE when i
 (`PolicyContext.ee`) and both forwards read the cached embeddings - 1 encoder image per slice and step instead of 12.
 `sync_every` spaces out the only host synchronisation of the loop (the all-stopped check).
 
-`use_graphs` (default on a GPU): the policy side of a steady-state step - the observation's state encoder, and the two transformer
-forwards over the 6-step window - is ~175 kernels of a few microseconds each; they are captured ONCE per batch size in two hipGraphs
-(`torch.cuda.CUDAGraph`) over static window buffers and replayed (same kernels, same arithmetic; the first `ctx` steps of an
-episode, whose read positions move, stay eager).
+`use_graphs` (default on a GPU): the policy side of a steady-state step - the observation's state encoder, and the ONE transformer
+forward with both heads over the 6-step window (from step `ctx` on the reference's two forwards read identical tokens, see
+`_predict`) - is ~110 kernels of a few microseconds each; the encoder call and that forward are captured ONCE per batch size in
+two hipGraphs (`torch.cuda.CUDAGraph`) over static window buffers and replayed (same kernels, same arithmetic; the first `ctx`
+steps of an episode, whose read positions move and which still need two forwards, stay eager).
 
 `rollout_rows` is the same loop with a per-row clock (rows of one batch at different episode times), which is what a
 batched tree search needs: the nodes selected in different images sit at different depths.
@@ -127,29 +128,30 @@ class GreedyEvaluator:
 
     # ---- hipGraph capture of the policy side ---------------------------------------------------------------
     def _capture(self, fn):
-        """Warm `fn` up on a side stream (library handles, autotuning, allocator), then capture one call of it.  A capture
-        that fails (a PyTorch build or op that cannot be captured) switches the evaluator back to eager policy calls - the same
-        kernels launched one by one - with a warning; the HIP env is not involved either way."""
-        try:
-            return self._capture_unguarded(fn)
-        except Exception as exc:                                # noqa: BLE001 - any capture failure means "run eager"
-            import warnings
-            warnings.warn(f"hipGraph capture of the policy failed ({type(exc).__name__}: {exc}); continuing with eager policy calls")
-            self.use_graphs = False
-            torch.cuda.synchronize(self.device)
-            return None, None
-
-    def _capture_unguarded(self, fn):
+        """Warm `fn` up on a side stream (library handles, autotuning, allocator), then capture one call of it.  The warm-up
+        calls run OUTSIDE any handler and are synchronised: a genuine HIP error (device-side assert, out of memory, launch
+        failure) propagates from here as what it is.  Only the capture step itself is guarded: a capture that fails (a PyTorch
+        build or op that cannot be captured) switches the evaluator back to eager policy calls - the same kernels launched one
+        by one - with a warning, after a synchronize that re-raises if the context did not survive; the HIP env is not
+        involved either way."""
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(3):
                 fn()
         torch.cuda.current_stream(self.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = fn()
-        return g, out
+        torch.cuda.synchronize(self.device)                     # warm-up errors surface here, not as "capture failed"
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            return g, out
+        except RuntimeError as exc:                             # capture refused: run eager
+            import warnings
+            warnings.warn(f"hipGraph capture of the policy failed ({type(exc).__name__}: {exc}); continuing with eager policy calls")
+            self.use_graphs = False
+            torch.cuda.synchronize(self.device)                 # raises if the failure left the context unusable
+            return None, None
 
     @torch.no_grad()
     def _graphed_encode(self, ob_src: torch.Tensor):
@@ -245,7 +247,9 @@ class GreedyEvaluator:
         t = tvec.clamp(max=T - 1)
         early = t < c
         lo = torch.where(early, torch.zeros_like(t), t - c)
-        idx = lo[:, None] + torch.arange(c, device=t.device)[None, :]                      # [n, c] window steps
+        # [n, c] window steps; an episode shorter than the context window (T < c) has the T-step window the scalar path's
+        # slice `[0:c]` of a T-step buffer yields (every row is `early` then)
+        idx = lo[:, None] + torch.arange(min(c, T), device=t.device)[None, :]
         pos_a = torch.where(early, t, torch.full_like(t, c - 1))
         pos_r = torch.where(early, t, torch.full_like(t, c - 2))
         rows = torch.arange(n, device=t.device)

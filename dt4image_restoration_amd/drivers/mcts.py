@@ -38,19 +38,42 @@ from .greedy import GreedyEvaluator, PolicyContext
 
 
 class NodePool:
-    """Device storage of node states: row `id` of x [cap, H*W] f32, z / u [cap, H*W] c64, T [cap] f32."""
+    """Device storage of node states: row `id` of x [cap, H*W] f32, z / u [cap, H*W] c64, T [cap] f32 (20 B per pixel and
+    node).  The pool GROWS on demand (geometrically, rows are copied once per doubling) instead of reserving every node a
+    search could ever create: 64 images x 64 rounds x 5 children at 256 x 256 would be 27 GB up front, most of it for rounds
+    whose selected node is terminal and expands nothing."""
 
-    def __init__(self, capacity: int, h: int, w: int, device):
-        self.h, self.w = h, w
-        self.x = torch.empty((capacity, h * w), dtype=torch.float32, device=device)
-        self.z = torch.empty((capacity, h * w), dtype=torch.complex64, device=device)
-        self.u = torch.empty((capacity, h * w), dtype=torch.complex64, device=device)
-        self.T = torch.empty((capacity,), dtype=torch.float32, device=device)
+    def __init__(self, capacity: int, h: int, w: int, device, max_capacity: Optional[int] = None):
+        self.h, self.w, self.device = h, w, device
+        self.max_capacity = max_capacity
+        self.x = self.z = self.u = self.T = None
         self.used = 0
+        self._resize(max(1, capacity))
+
+    def _resize(self, capacity: int) -> None:
+        px = self.h * self.w
+        try:
+            x = torch.empty((capacity, px), dtype=torch.float32, device=self.device)
+            z = torch.empty((capacity, px), dtype=torch.complex64, device=self.device)
+            u = torch.empty((capacity, px), dtype=torch.complex64, device=self.device)
+            T = torch.empty((capacity,), dtype=torch.float32, device=self.device)
+        except RuntimeError as exc:                             # out of device memory: say what the search needs
+            raise RuntimeError(f"tree-search node pool: {capacity} node states of {self.h}x{self.w} need "
+                               f"{capacity * (px * 20 + 4)} bytes of device memory ({exc})") from exc
+        if self.used:
+            x[:self.used] = self.x[:self.used]; z[:self.used] = self.z[:self.used]
+            u[:self.used] = self.u[:self.used]; T[:self.used] = self.T[:self.used]
+        self.x, self.z, self.u, self.T = x, z, u, T
 
     def alloc(self, count: int) -> torch.Tensor:
-        if self.used + count > self.x.shape[0]:
-            raise RuntimeError("node pool exhausted")
+        need = self.used + count
+        if need > self.x.shape[0]:
+            cap = max(need, 2 * self.x.shape[0])
+            if self.max_capacity is not None:
+                if need > self.max_capacity:
+                    raise RuntimeError("node pool exhausted")
+                cap = min(cap, self.max_capacity)
+            self._resize(cap)
         ids = torch.arange(self.used, self.used + count, device=self.x.device)
         self.used += count
         return ids
@@ -188,18 +211,27 @@ class MCTS:
 
     # -- search --------------------------------------------------------------------------------------------------
     def run_batch(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor,
-                  first_state: Optional[torch.Tensor] = None):
-        """B images at once (one tree each).  Returns (best PSNR [B,1] CPU, list of B roots)."""
+                  first_state: Optional[torch.Tensor] = None, first_image: int = 0):
+        """B images at once (one tree each).  Returns (best PSNR [B,1] CPU, list of B roots).
+        first_image: index of this batch's first image in the whole job - image i samples its children from the stream seeded
+        with (seed, first_image + i), so a shard of a job searches exactly the trees the unsharded job does."""
         k, dev, ev = self.k, self.ev.device, self.ev
         mat = {key: torch.as_tensor(v) for key, v in mat.items()}
         B = mat["gt"].shape[0]
         t_start = _time.perf_counter()
         # engine of B rows for the rollouts, engine of B*k rows for the expansions (the k children of an image are adjacent)
-        rep = {key: (v.repeat_interleave(k, dim=0) if key != "mask" and v.dim() > 2 else v) for key, v in mat.items()}
+        # (a per-image mask [B,H,W] - the reference reads one per .mat file - is repeated like the images; one shared [H,W] mask is not)
+        hw = mat["gt"].shape[-2] * mat["gt"].shape[-1]
+        def replicate(key, v):
+            if key == "mask":
+                return v.reshape(-1, *v.shape[-2:]).repeat_interleave(k, dim=0) if v.numel() != hw else v
+            return v.repeat_interleave(k, dim=0) if v.dim() > 2 else v
+        rep = {key: replicate(key, v) for key, v in mat.items()}
         st_roll = self.env.reset(mat, dev)
         st_exp = self.env.reset(rep, dev)
         h, w = st_roll["z"].shape[-2:]
-        pool = NodePool(B * (1 + k * self.rounds), h, w, dev)
+        # roots + the first rounds' children; grows when the trees do (NodePool); the bound is every round expanding every image
+        pool = NodePool(B * (1 + k * min(self.rounds, 8)), h, w, dev, max_capacity=B * (1 + k * self.rounds))
         cache_emb = ev.cache_state_embeddings
 
         def observation(x):                                      # -> (emb [n,E] or None, ob [n,16384] or None)
@@ -217,7 +249,7 @@ class MCTS:
         rtg0 = rtg.reshape(B, 1).to(dev).float()
         roots = [Node(pool, int(root_ids[b]), 0, 1.0, None, 0, None, None if emb0 is None else emb0[b],
                       None if ob0 is None else ob0[b], rtg0[b], 0) for b in range(B)]
-        gens = [torch.Generator().manual_seed(self.seed * 1000003 + b) for b in range(B)]
+        gens = [torch.Generator().manual_seed(self.seed * 1000003 + first_image + b) for b in range(B)]
         order = list(ev.model.action_range.keys())
         n_rollouts = 0
         for rnd in range(self.rounds):
@@ -277,11 +309,10 @@ class MCTS:
                 starts = torch.tensor([nd.time + 1 for nd in sel], dtype=torch.int64)
                 reward, _ = ev.rollout_rows(st_roll, act, prtg, starts, ctx, scorer=self.scorer,
                                             active=torch.tensor(need))
-                finals = st_roll["x"].clone()
                 for b in range(B):
                     if need[b]:
                         sel[b].rollout_reward = float(reward[b])
-                        sel[b].final_x = finals[b:b + 1]
+                        sel[b].final_x = st_roll["x"][b:b + 1].clone()      # this row only (a view would pin the whole batch)
                         n_rollouts += 1
             for b in range(B):
                 if expand[b]:

@@ -84,7 +84,7 @@ def run_sharded_mcts(tree, total: int, load_shard: Callable[[int, int], Tuple[Di
     t0 = time.perf_counter()
     if b > a:
         mat, rtg, task = load_shard(a, b)
-        psnr, _ = tree.run_batch(mat, rtg, task)
+        psnr, _ = tree.run_batch(mat, rtg, task, first_image=a)      # per-image sampling streams follow the GLOBAL image index
         local = psnr.to(dev).float()
         rollouts = float(tree.last_stats["rollouts"])
     else:

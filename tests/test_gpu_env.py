@@ -228,16 +228,18 @@ def test_full_size_batch64_properties(denoiser):
     st2, _ = env2.step(st2, {"T": torch.zeros(2), "mu": torch.full((2,), 0.3), "sigma_d": torch.full((2,), 0.05)})
     for k in ("x", "z", "u"):
         assert float((st[k][sel] - st2[k]).abs().max()) < 2e-5, k
-    # and one slice against the CPU oracle after the same 3 iterations: PSNR within tolerance
+    # and ALL 64 slices against the CPU oracle after the same 3 iterations (the plan the headline bench times: every slice, not
+    # a sample): PSNR within tolerance, images to f32 summation-order rounding
     sd = O.torch_weights(denoiser.weights)
-    d1 = {k: (v[:1] if k != "mask" else v) for k, v in data.items()}
-    so = O.reset(d1)
+    so = O.reset(data)
     for t in range(2):
-        so, _ = O.admm_step(sd, so, torch.from_numpy(mu_tab[:1, t].copy()), torch.from_numpy(sg_tab[:1, t].copy()))
-    so, _ = O.admm_step(sd, so, torch.tensor([0.3]), torch.tensor([0.05]))
-    dp = abs(float(O.psnr(so["x"], so["gt"])) - float(env.compute_reward(st["x"][:1], st["gt"][:1])))
-    assert dp < PSNR_TOL_DB
-    np.testing.assert_allclose(st["x"][:1].cpu().numpy(), so["x"].numpy(), rtol=0, atol=2e-5)
+        so, _ = O.admm_step(sd, so, torch.from_numpy(mu_tab[:, t].copy()), torch.from_numpy(sg_tab[:, t].copy()))
+    so, _ = O.admm_step(sd, so, torch.full((n,), 0.3), torch.full((n,), 0.05))
+    dp = (O.psnr(so["x"], so["gt"]).reshape(-1) - env.compute_reward(st["x"], st["gt"]).reshape(-1)).abs()
+    assert float(dp.max()) < PSNR_TOL_DB, dp
+    # FLOAT TOLERANCE: f32 summation order (Winograd F(4x4) tiling vs ATen's direct sum) over 3 iterations of the 27-layer network
+    np.testing.assert_allclose(st["x"].cpu().numpy(), so["x"].numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(torch.view_as_real(st["z"]).cpu().numpy(), torch.view_as_real(so["z"]).numpy(), rtol=0, atol=3e-5)
 
 
 # ---- BASELINE configs[4] geometry: 512x512, 8x undersampling (f32 path; the bf16 conv variant is a later round) ---------
@@ -270,8 +272,8 @@ def test_512_accel8_matches_oracle_and_properties(denoiser):
 # ---- round-2 additions: the holes the round-1 review listed ------------------------------------------------------------
 def test_512_accel8_bf16_convs_match_bf16_oracle(denoiser):
     """BASELINE configs[4] AS STATED: 512x512, 8x undersampling, bf16 denoiser convs.  Two slices x 3 iterations against the
-    oracle's bf16-operand mode (same rounding points), plus this mode's stated bound on the offset to the f32 reference
-    arithmetic (0.02 dB)."""
+    oracle's bf16-operand mode (same rounding points), plus north_star's +-0.01 dB bound on the offset to the f32 reference
+    arithmetic (measured 0.003-0.006 dB)."""
     from dt4image_restoration_amd.engine import PnPEngine
     from oracle import pnp_oracle as O
     n, h, w = 2, 512, 512
@@ -292,7 +294,7 @@ def test_512_accel8_bf16_convs_match_bf16_oracle(denoiser):
         sf, _ = O.admm_step(sd, sf, mu, sg)
         p = e.psnr(x, gt).cpu()
         assert float((p - O.psnr(sb["x"], sb["gt"]).reshape(-1)).abs().max()) < PSNR_TOL_DB
-        assert float((p - O.psnr(sf["x"], sf["gt"]).reshape(-1)).abs().max()) < 0.02
+        assert float((p - O.psnr(sf["x"], sf["gt"]).reshape(-1)).abs().max()) < PSNR_TOL_DB
     # FLOAT TOLERANCE: bf16 operand rounding flips (2^-9 relative) reach the image at ~1e-3 (test_gpu_kernels.py)
     assert float((x.cpu() - sb["x"]).abs().max()) < 3e-3
     assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0

@@ -183,3 +183,36 @@ def test_shard_range_partitions():
         assert seen == list(range(total))
     with pytest.raises(ValueError):
         sharding.shard_range(4, 4, 4)
+
+
+def test_checkpoint_file_ingest_on_the_cpu(tmp_path):
+    """The reference's weight ingest (noise.py:146-148: `net.load_state_dict(torch.load(ckpt_path))`): a torch.save'd
+    OrderedDict of the 56 tensors loads through `UNetDenoiser2D(ckpt_path=...)` into exactly the arrays it was written from
+    (no GPU needed up to here: the engine is created on first use), a file with a missing / misshapen tensor is rejected, and
+    the policy's 85-key checkpoint round-trips through `torch.load` + `load_state_dict` like eval.py:20,27 does."""
+    import collections
+    import torch
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.policy import DecisionTransformer, DecisionTransformerConfig
+    sd = weights.generate_unet_weights(3, "torch_default")
+    ck = tmp_path / "unet-nm.pt"
+    torch.save(collections.OrderedDict((k, torch.from_numpy(v.copy())) for k, v in sd.items()), ck)
+    den = UNetDenoiser2D(ckpt_path=str(ck))
+    assert list(den.weights) == unet_spec.STATE_DICT_KEYS
+    for k in sd:
+        assert den.weights[k].dtype == np.float32 and np.array_equal(den.weights[k], sd[k]), k
+    bad = collections.OrderedDict((k, torch.from_numpy(v.copy())) for k, v in sd.items())
+    bad.pop("down2.mpconv.1.conv-1.conv2d.bias")
+    torch.save(bad, tmp_path / "bad.pt")
+    with pytest.raises(KeyError):
+        UNetDenoiser2D(ckpt_path=str(tmp_path / "bad.pt"))
+    with pytest.raises(ValueError):
+        UNetDenoiser2D()                                  # neither a path nor a mapping (noise.py:143-145)
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    psd = weights.generate_policy_weights(m, 5, t_bias=-1.0, head_gain=8.0)
+    assert len(psd) == 85
+    torch.save(psd, tmp_path / "model_experiment_1.pt")
+    m2 = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m2.load_state_dict(torch.load(tmp_path / "model_experiment_1.pt", map_location="cpu"))
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, torch.as_tensor(psd[k])), k
