@@ -572,6 +572,7 @@ Tuning tuning_from_env() {
     t.no_f4_fused_last = getenv("PNP_NO_F4_FUSED_LAST") != nullptr;
     t.no_f4_fused_first = getenv("PNP_NO_F4_FUSED_FIRST") != nullptr;
     if (const char* v = getenv("PNP_WINO_F4_MT16")) t.f4_mt16 = atoi(v);
+    if (const char* v = getenv("PNP_WINO_F4_ORDER")) t.f4_order = atoi(v) != 0;
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;
 }

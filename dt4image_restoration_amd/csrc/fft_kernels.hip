@@ -18,6 +18,7 @@
 //   rows-inverse : row IFFT -> z;  u += x - z                         (reads 20 B/px, writes 16)
 // Twiddles come from a host-computed (double precision) table.
 #include "pnp_internal.h"
+#include <cstdlib>
 
 namespace pnp {
 
@@ -268,19 +269,22 @@ __device__ __forceinline__ void fft256_radix16_inplace(float2* buf, const float2
 static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in the row passes
 
 // MODE 0 generic (in -> out, index shifts), 1 ADMM forward (x + u -> work), 2 ADMM inverse (work -> z, u)
-template <int MODE, int LC>
+// R16 (256-point rows of the ADMM passes): SIXTEEN rows per workgroup, each as two radix-16 passes in place in one skewed buffer
+// (fft256_radix16_inplace: every thread owns a butterfly, 2 LDS round trips per transform instead of 4, and the skew keeps the
+// Stockham strides off each other's banks - the radix-4 passes over unpadded 256-element lines spent 0.40 of their LDS cycles
+// in bank conflicts, profiles/r02_pmc_current.md).
+template <int MODE, int LC, bool R16 = false>
 __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2* out,
                                                        const float* __restrict__ x, float2* __restrict__ u,
                                                        const float2* __restrict__ twg, const float* __restrict__ tact,
                                                        int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    // (two radix-16 passes for 256-point rows measured 0.0506 against 0.0489 ms for the radix-4 passes: with 8 rows per
-    // workgroup only half the threads own a butterfly; the switch stays for experiments)
-    constexpr bool R16 = false && LC == 256;
+    static_assert(!R16 || (LC == 256 && MODE != 0), "radix-16 rows: the 256-point ADMM passes");
+    constexpr int RE = R16 ? 16 * 256 : ROW_ELEMS;         // elements per workgroup (R16: 16 rows, so that all 256 threads own a butterfly)
     auto slot = [&](int e) { return R16 ? (e >> 8) * SK256_LS + sk256(e & 255) : e; };
     float2* buf0 = smem;
     float2* buf1 = smem + (R16 ? 0 : rpb * W);
-    float2* tw = smem + (R16 ? (ROW_ELEMS / 256) * SK256_LS : 2 * rpb * W);
+    float2* tw = smem + (R16 ? (RE / 256) * SK256_LS : 2 * rpb * W);
     const int blocks_per_img = H / rpb;
     const int n = blockIdx.x / blocks_per_img;
     const int y0 = (blockIdx.x % blocks_per_img) * rpb;
@@ -312,9 +316,9 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     __syncthreads();
     const bool inv = (MODE == 2) || (MODE == 0 && inverse);
     float2* res;
-    if constexpr (R16) {                                   // W == 256, 8 rows per workgroup (checked by the launcher)
-        if (inv) fft256_radix16_inplace<true, ROW_ELEMS / 256>(buf0, tw);
-        else fft256_radix16_inplace<false, ROW_ELEMS / 256>(buf0, tw);
+    if constexpr (R16) {                                   // W == 256, 16 rows per workgroup (checked by the launcher)
+        if constexpr (MODE == 2) fft256_radix16_inplace<true, RE / 256>(buf0, tw);
+        else fft256_radix16_inplace<false, RE / 256>(buf0, tw);
         res = buf0;
     } else if constexpr (LC > 0) {                         // W == LC, rpb == ROW_ELEMS / LC (checked by the launcher)
         if constexpr (MODE == 2) res = fft_lines_ct<true, LC, ROW_ELEMS / LC, LC>(buf0, buf1, tw);
@@ -712,8 +716,19 @@ hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, in
                        nullptr, nullptr, H, W, cw, inverse, shift_in, shift_out);
     return hipGetLastError();
 }
+// 256-point rows: the radix-16 variant (16 rows per workgroup); PNP_FFT_ROWS_R4 (experiments) keeps the radix-4 passes
+static bool rows_r16(int H, int W) {
+    static const bool off = getenv("PNP_FFT_ROWS_R4") != nullptr;
+    return !off && W == 256 && H % 16 == 0;
+}
+
 hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* work, const float2* tw, const float* tact,
                                     int N, int H, int W, hipStream_t s) {
+    if (rows_r16(H, W)) {
+        hipLaunchKernelGGL((fft_rows_kernel<1, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
+                           nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 16, 0, 0, 0);
+        return hipGetLastError();
+    }
     const int rpb = rows_per_block(H, W);
     const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
 #define PNP_ROWS_FWD(LC_)                                                                                      \
@@ -746,6 +761,11 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
 }
 hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
                                     const float* tact, int N, int H, int W, hipStream_t s) {
+    if (rows_r16(H, W)) {
+        hipLaunchKernelGGL((fft_rows_kernel<2, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
+                           work, z, x, u, tw, tact, H, W, 16, 1, 0, 0);
+        return hipGetLastError();
+    }
     const int rpb = rows_per_block(H, W);
     const size_t lds = (size_t)(2 * rpb * W + W) * sizeof(float2);
 #define PNP_ROWS_INV(LC_)                                                                                      \

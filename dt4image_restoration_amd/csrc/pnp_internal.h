@@ -23,6 +23,7 @@ struct Tuning {
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
     int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
                                   // 64-channel-block layer on 16-tile M-blocks
+    int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
                                   // needs a chip-filling batch to beat the three-launch path: 64.1 vs 78.8 us at 256 slices, 48.9 vs 34.9 at 64)
@@ -63,6 +64,7 @@ struct ConvArgs {
     int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
     int bf16;            // direct kernel: bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate
+    int order;           // F(4x4): blockIdx -> tile order (wino4_decode), from the plan
 #ifdef PNP_STAMPS
     int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
 #endif
@@ -98,6 +100,7 @@ struct WinoPlan {
     int stack;         // F(4x4) on 16 x 16 images: two slices stacked into one 32-tile workgroup
     int mt;            // F(4x4): tiles per workgroup (32, or 16 = two independent 4-wave workgroups per CU)
     int phased;        // F(4x4), 64-channel blocks, plain source: the two tile halves run half a chunk apart (conv3x3_wino4p_kernel)
+    int order;         // F(4x4): 1 = every XCD walks a contiguous range of spatial tiles (halo pixels shared through its L2), 0 = tiles dealt round-robin
 };
 // `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)
 WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t);

@@ -159,6 +159,26 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
     }
 }
 
+// ---- blockIdx -> (channel block, spatial tile).  Blocks b and b + 8 share an XCD under round-robin placement (speed only, never
+// correctness).  Both orders run the channel blocks of one spatial tile back to back on ONE XCD, so the patch they all read comes
+// into that L2 once.  order 0 (rounds 1-2): XCD k takes the spatial tiles k, k + 8, k + 16, ... - a tile's neighbours sit on other
+// XCDs and every halo row / column is fetched from the fabric twice.  order 1: XCD k takes the CONTIGUOUS range of tiles
+// [k * ceil(ntiles / 8), ...), in image order, so consecutive workgroups of an XCD are neighbours in the image and their shared halo
+// pixels are L2 hits.
+__device__ __forceinline__ void wino4_decode(int bid, int ny, int ntiles, int order, int& cby, int& bt) {
+    if (order == 0) {
+        const int grp = bid / (8 * ny), rem = bid % (8 * ny);
+        cby = rem >> 3;
+        bt = grp * 8 + (rem & 7);
+    } else {
+        const int xcd = bid & 7, slot = bid >> 3;          // slot: position in this XCD's queue
+        const int tpx = (ntiles + 7) >> 3;                 // tiles per XCD
+        const int lt = slot / ny;
+        cby = slot - lt * ny;
+        bt = lt < tpx ? xcd * tpx + lt : ntiles;           // (grid padding)
+    }
+}
+
 // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1],
 // lane-local: accumulator register r of acc[6i + j] is M[i][j] of tile 16 th + 4 tg + r, channel 16 cb + cl.  Two tiles at a
 // time in packed f32 (registers (0,1) and (2,3) of an accumulator are aligned pairs).  + bias, LeakyReLU, NHWC stores (16
@@ -327,10 +347,17 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
     constexpr int LITEMS = LH * LW * PPP;
     constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
-    constexpr int NRAW = (UP2 && NITL > NIT) ? NITL : NIT;
+    // SPLIT (64-channel upsample + concat variants): a skip chunk's NIT staging loads go out in TWO half-batches - the first at the
+    // start of the previous chunk's MFMA phase, parked half way through it, where the second goes out - so that only NIT / 2
+    // staging registers are live beside the 144 accumulators and the B ring (the whole batch held across the phase spilled 22
+    // registers into scratch inside the chunk loop)
+    constexpr bool SPLIT = UP2 && WN == 2;
+    constexpr int NH0 = SPLIT ? (NIT + 1) / 2 : NIT;       // items of the first half-batch (all of them without SPLIT)
+    constexpr int NRAW = SPLIT ? (NH0 > NITL ? NH0 : NITL) : ((UP2 && NITL > NIT) ? NITL : NIT);
     constexpr int S = CK / 4;                          // MFMAs (4 channels each) per frequency and chunk
-    constexpr int PF = WN == 2 ? 9 : 12;                              // B fragments in flight in the MFMA loop (must divide 36: slots line up
-                                                       // across chunks) ...
+    constexpr int PF = WN == 2 ? 9 : 12;              // B fragments in flight in the MFMA loop (must divide 36: slots line up
+                                                       // across chunks; the 16-tile upsample variant spilled 22 registers into scratch
+                                                       // INSIDE its chunk loop with a ring of 9) ...
     constexpr int KEEP = 3;                            // ... of which only the first KEEP are loaded across the chunk boundary (the
                                                        // input transform needs the registers); the rest go out after the transform
     constexpr int PLANE = MT * CKP;                    // floats per frequency plane of V
@@ -365,10 +392,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     // layer in all, stays L2-resident - measured 4-6 % SLOWER on every layer: the weights stream well from the Infinity Cache.)
     const int ny = a.Cout / (32 * WN);
     const int bid = blockIdx.x;
-    const int grp = bid / (8 * ny), rem = bid % (8 * ny);
-    const int cby = rem >> 3;                              // this workgroup's block of 32 * WN channels
-    int bt = grp * 8 + (rem & 7);                          // spatial tile index
-    if (bt >= a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N)) return;
+    const int ntl = a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N);
+    int cby, bt;                                           // this workgroup's block of 32 * WN channels, its spatial tile index
+    wino4_decode(bid, ny, ntl, a.order, cby, bt);
+    if (bt >= ntl) return;
     const int tx0 = (bt % a.tilesX) * TW;
     bt /= a.tilesX;
     const int ty0 = (bt % a.tilesY) * TH;
@@ -428,8 +455,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     };
 
     float4 raw[NRAW];
-    auto issue = [&](int c) {
-        if (UP2 && c >= nskip) {                           // low-res region of an upsampled chunk
+    // half: 0 = first half-batch (without SPLIT: everything), 1 = second half-batch of a skip chunk (SPLIT only)
+    auto issue = [&](int c, int half = 0) {
+        if (UP2 && c >= nskip) {                           // low-res region of an upsampled chunk (one batch, NITL <= NRAW items)
+            if (half != 0) return;
             const int soff = (c * CK - a.Cskip) * 4;
 #pragma unroll
             for (int k = 0; k < NITL; ++k)
@@ -437,15 +466,22 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             return;
         }
         const int soff = c * CK * 4;
+        if (half == 0) {
 #pragma unroll
-        for (int k = 0; k < NIT; ++k)
-            raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
+            for (int k = 0; k < NH0; ++k)
+                raw[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
+        } else {
+#pragma unroll
+            for (int k = NH0; k < NIT; ++k)
+                raw[k - NH0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voff[k], soff, 0));
+        }
     };
     // registers -> LDS: the patch itself (plain chunks) or the low-res source region (upsampled chunks).  Runs right after a
     // wave's MFMA phase of the previous chunk - the patch and the low-res region are dead from the post-transform barrier on -
     // so it overlaps the partner waves' MFMAs and needs no barrier of its own.
-    auto park = [&](int c) {
+    auto park = [&](int c, int half = 0) {
         if (UP2 && c >= nskip) {
+            if (half != 0) return;
 #pragma unroll
             for (int k = 0; k < NITL; ++k) {
                 const int idx = tid + k * NT_;
@@ -453,10 +489,18 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             }
             return;
         }
+        if (half == 0) {
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * NT_;
-            if (idx < ITEMS) put_patch(ldst + k * (NT_ / PPP) * CKQ, raw[k]);
+            for (int k = 0; k < NH0; ++k) {
+                const int idx = tid + k * NT_;
+                if (idx < ITEMS) put_patch(ldst + k * (NT_ / PPP) * CKQ, raw[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = NH0; k < NIT; ++k) {
+                const int idx = tid + k * NT_;
+                if (idx < ITEMS) put_patch(ldst + k * (NT_ / PPP) * CKQ, raw[k - NH0]);
+            }
         }
     };
     // upsampled chunk: interpolate the patch from the parked low-res region (ATen upsample_bilinear2d, align_corners=True:
@@ -574,7 +618,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         }
     }
     if constexpr (FIRST) first_patch(0);
-    else { issue(0); park(0); }
+    else {
+        issue(0); park(0);
+        if constexpr (SPLIT) { issue(0, 1); park(0, 1); }
+    }
 
     // this thread's transform item: tile tq of the workgroup's 32 tiles (TC per row), channels [2*hc, 2*hc+2), frequency
     // column group tj (first half of the waves: columns 0..2, second half: columns 3..5; all six rows).  HCN lanes cover a
@@ -599,10 +646,25 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
 
     typedef typename std::conditional<WN == 2, float4, float2>::type frag_t;      // S channels of one lane's A / B fragment
     const size_t stream = (size_t)nchunks * 36 * 64 + kW4Tail / S;                // fragments per 16-channel block's stream
-    const frag_t* bptr = reinterpret_cast<const frag_t*>(a.wpack) + (size_t)cb * stream + lane;
+    // Upsample + concat variants: B fragments come through a buffer descriptor over this wave's stream - per-lane offset lane *
+    // sizeof(frag_t) (one register, constant), fragment offset SCALAR: no 64-bit vector address arithmetic in the MFMA loop
+    // (global_load costs two v_add per ~4 loads on the port the f32 MFMAs need, and an address register pair): -2...3.5 % on those
+    // layers.  The plain variants measured 3-9 % SLOWER that way (the B stream is their dominant traffic and global_load streams
+    // it faster than offen buffer loads) and keep global loads.
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const frag_t*>(a.wpack) + (size_t)cb * stream), 0, (int)(stream * sizeof(frag_t)), 0x00020000);
+    const int boff = lane * (int)sizeof(frag_t);
+    const frag_t* const bptr = reinterpret_cast<const frag_t*>(a.wpack) + (size_t)cb * stream + lane;
+    // fragment i of the chunk whose first fragment is number f0 of the stream / sits at bp (both wave-uniform; the global-load
+    // form keeps ONE base pointer per chunk and immediate offsets - an address computed per load costs vector instructions)
+    auto bfrag = [&](const frag_t* bp, int f0, int i) -> frag_t {
+        if constexpr (!UP2) return bp[i * 64];
+        else if constexpr (WN == 2) return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rB, boff, (f0 + i) * (64 * 16), 0));
+        else return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b64(rB, boff, (f0 + i) * (64 * 8), 0));
+    };
     frag_t bq[PF];
 #pragma unroll
-    for (int p = 0; p < KEEP; ++p) bq[p] = bptr[p * 64];
+    for (int p = 0; p < KEEP; ++p) bq[p] = bfrag(bptr, 0, p);
     const int aoff = (16 * th + cl) * CKP + S * swz(cl, tg);                      // this lane's fragment of V[0]
 
 #ifdef PNP_STAMPS
@@ -634,9 +696,10 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         else wino4_input_transform<1, PW, CKQ, PLANE>(patch + win, V + vout);
         if constexpr (NT_ == 256) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        const frag_t* bp = bptr + (size_t)c * 36 * 64;
+        const frag_t* bp = bptr + (size_t)c * 36 * 64;     // this chunk's fragments
+        const int bf0 = c * 36;
 #pragma unroll
-        for (int p = KEEP; p < PF; ++p) bq[p] = bp[p * 64];
+        for (int p = KEEP; p < PF; ++p) bq[p] = bfrag(bp, bf0, p);
         if constexpr (WN == 2) { if (c + 1 < nchunks) issue(c + 1); }   // next chunk's loads fly under this chunk's MFMAs
         __syncthreads();
 #ifdef PNP_STAMPS
@@ -659,16 +722,19 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
                 acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[xi], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT) {                         // half way: park the first half-batch, send the second
+                if (xi == 17 && c + 1 < nchunks) { park(c + 1, 0); issue(c + 1, 1); }
+            }
             // refill the slot just read: this chunk's fragment xi + PF, or one of the next chunk's first KEEP (the stream is
             // contiguous across chunks; tail zero-padded)
-            if (xi + PF < 36 + KEEP) bq[xi % PF] = bp[(xi + PF) * 64];
+            if (xi + PF < 36 + KEEP) bq[xi % PF] = bfrag(bp, bf0, xi + PF);
         }
 #ifdef PNP_STAMPS
         { const unsigned long long t = W4T(); st_mfma += t - st_tmp; }
 #endif
         if (c + 1 < nchunks) {
             if constexpr (FIRST) first_patch(c + 1);
-            else park(c + 1);
+            else park(c + 1, SPLIT ? 1 : 0);
         }
     }
 #ifdef PNP_STAMPS
@@ -733,10 +799,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4p_kernel(const ConvArgs a
 
     const int ny = a.Cout / 64;
     const int bid = blockIdx.x;
-    const int grpb = bid / (8 * ny), rem = bid % (8 * ny);
-    const int cby = rem >> 3;                              // this workgroup's block of 64 channels
-    int bt = grpb * 8 + (rem & 7);                         // spatial tile index (XCD-aware order, see conv3x3_wino4_kernel)
-    if (bt >= a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N)) return;
+    const int ntl = a.tilesX * a.tilesY * (STK ? (a.N + 1) / 2 : a.N);
+    int cby, bt;                                           // this workgroup's block of 64 channels, its spatial tile index (XCD-aware
+    wino4_decode(bid, ny, ntl, a.order, cby, bt);          // order, see conv3x3_wino4_kernel)
+    if (bt >= ntl) return;
     const int tx0 = (bt % a.tilesX) * TW;
     bt /= a.tilesX;
     const int ty0 = (bt % a.tilesY) * TH;
@@ -794,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4p_kernel(const ConvArgs a
     for (int k = 0; k < 36; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const size_t stream = (size_t)nchunks * 36 * 64 + kW4Tail / S;                // fragments per 16-channel block's stream
-    const float4* bptr = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * stream + lane;
+    const float4* const bptr = reinterpret_cast<const float4*>(a.wpack) + (size_t)cb * stream + lane;
     float4 bq[PF];
 #pragma unroll
     for (int p = 0; p < KEEP; ++p) bq[p] = bptr[p * 64];
@@ -923,6 +989,7 @@ hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int s
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
+    a.order = p.order;
 #ifdef PNP_STAMPS
     a.stamp_slot = g_w4_slot++;
 #endif

@@ -82,6 +82,7 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
         W >= 16 && H >= 16 && (W >= 32 || H >= 32 || (W == 16 && H == 16 && src_mode == SRC_PLAIN && N >= 2))) {
         WinoPlan f{};
         f.algo = 4;
+        f.order = t.f4_order;
         f.tw = W >= 32 ? 32 : 16;
         f.th = f.tw == 32 ? 16 : 32;
         f.bn = 64; f.wm = 1; f.wn = 2; f.ck = 16;
