@@ -125,10 +125,10 @@ def greedy_leg(args, dev, sd_np, n, h, w, world):
             shard[(a, b)] = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in p.items()}
         return shard[(a, b)], torch.full((b - a,), D.normalised_rtg(10.0)), torch.full((b - a,), 4)
 
-    run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize)                    # warm-up episode
+    run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize, pipeline=args.pipeline)      # warm-up episode
     secs, res = [], None
     for _ in range(max(1, min(args.reps, 5))):
-        res = run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize)
+        res = run_sharded_greedy(ev, total, load_shard, sync=torch.cuda.synchronize, pipeline=args.pipeline)
         secs.append(res.seconds)
     secs.sort()
     med = secs[(len(secs) - 1) // 2]
@@ -136,6 +136,8 @@ def greedy_leg(args, dev, sd_np, n, h, w, world):
                     "heads over the 6-step context - the reference's two forwards read identical tokens from step 6 on -, state embeddings "
                     "cached, both captured in hipGraphs; the first 6 steps two eager forwards) + one pnp_step, all slices of a rank as one batch; reset, first policy call "
                     "and the final PSNR gather included",
+            "pipeline": (f"{args.pipeline} sub-batches per rank on their own streams, one's policy call under another's env step"
+                         if args.pipeline > 1 else "off (one batch per rank: policy and env step alternate on one stream)"),
             "steps": res.steps, "slices": total, "seconds_median": round(med, 5), "ms_per_step": round(1e3 * med / max(res.steps, 1), 4),
             "batch_iterations_per_sec": round(world * res.steps / med, 3), "episodes_timed": len(secs),
             "psnr_mean_db": round(float(res.reward.mean()), 4), "stop_iteration_mean": float(res.stop_time.float().mean())}
@@ -160,6 +162,11 @@ def main():
                     help="engine (headline): K pnp_step calls driven by a parameter table; greedy: BASELINE configs[2]'s DT-driven "
                          "sharded episode end to end is the timed thing (value = its batch-iterations/s)")
     ap.add_argument("--no-greedy", action="store_true", help="skip the end-to-end DT-driven leg of the default line")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="DT-driven leg: sub-batches per rank that advance on their own streams (GreedyEvaluator.run_pipelined; "
+                         "1 = off, the default: two sub-batches of 32 measured 9.64 against 9.39 ms per step - the policy's chain "
+                         "of ~110 small kernels stretches under the other sub-batch's convs and two 32-slice steps cost more than "
+                         "one 64-slice step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=16)
     ap.add_argument("--cpu-iters", type=int, default=6)

@@ -26,7 +26,7 @@ class UNetDenoiser2D:
                 raise ValueError("Default ckpt not found, you have to provide a ckpt path")
             state_dict = torch.load(ckpt_path, map_location="cpu")
         self.weights: Dict[str, np.ndarray] = check_state_dict(state_dict)
-        self._engines: Dict[Tuple[int, int, int, int], PnPEngine] = {}
+        self._engines: Dict[Tuple[int, int, int, int, int], PnPEngine] = {}
         self.bf16_convs = bool(bf16_convs)
 
     @classmethod
@@ -41,8 +41,10 @@ class UNetDenoiser2D:
     def eval(self):
         return self
 
-    def engine_for(self, n: int, h: int, w: int, device_index: int) -> PnPEngine:
-        key = (n, h, w, device_index)
+    def engine_for(self, n: int, h: int, w: int, device_index: int, replica: int = 0) -> PnPEngine:
+        """The handle for [n, h, w] on that device.  `replica` > 0: another handle of the same shape with its own workspace
+        and k-space constants - what two sub-batches stepped concurrently on two streams need (drivers/greedy.run_pipelined)."""
+        key = (n, h, w, device_index, replica)
         eng = self._engines.get(key)
         if eng is None:
             eng = PnPEngine(n, h, w, device=device_index, bf16_convs=self.bf16_convs)

@@ -57,6 +57,7 @@ class PolicyContext:
     et: torch.Tensor            # [n, T, 1] time steps
     ek: torch.Tensor            # [n, T] task token
     ee: Optional[torch.Tensor]  # [n, T, E] cached state-encoder outputs of `es` (None: re-encode like the reference)
+    tag: int = 0                # which concurrently running sub-batch this context belongs to (its own captured graphs / static buffers)
 
     def window(self, lo: int, hi: int):
         return (self.er[:, lo:hi], self.es[:, lo:hi], self.et[:, lo:hi], self.ek[:, lo:hi], self.ea[:, lo:hi],
@@ -154,9 +155,9 @@ class GreedyEvaluator:
             return None, None
 
     @torch.no_grad()
-    def _graphed_encode(self, ob_src: torch.Tensor):
+    def _graphed_encode(self, ob_src: torch.Tensor, tag: int = 0):
         """`encode_states(policy_observation(x))` through a captured graph; x [n,1,H,W] float32 on the device."""
-        key = ("enc", tuple(ob_src.shape))
+        key = ("enc", tuple(ob_src.shape), tag)
         ent = self._graphs.get(key)
         if ent is None:
             xs = torch.zeros_like(ob_src)
@@ -175,7 +176,7 @@ class GreedyEvaluator:
         """`_predict` for time >= ctx (window [time-ctx, time), action read at the last position, rtg at the second-to-last)."""
         c = self.context_length
         n = ctx.ea.shape[0]
-        key = ("predict", n)
+        key = ("predict", n, ctx.tag)
         ent = self._graphs.get(key)
         if ent is None:
             er, _, et, ek, ea, ee = (t.clone() if t is not None else None for t in ctx.window(0, c))
@@ -280,15 +281,25 @@ class GreedyEvaluator:
     def rollout(self, states, action, pred_rtg, start_time: int, ctx: PolicyContext, scorer=None):
         """eval.py:189-220 from `start_time`: step, observe, re-plan, until every slice stopped or max_timesteps.
         Returns (reward [N,1] CPU, stop_time [N]).  `scorer(states) -> [N]` replaces PSNR (no-reference rollouts)."""
+        out: Dict[str, torch.Tensor] = {}
+        for _ in self._rollout_phases(states, action, pred_rtg, start_time, ctx, scorer, self.env, out):
+            pass
+        return out["reward"], out["stop_time"]
+
+    def _rollout_phases(self, states, action, pred_rtg, start_time: int, ctx: PolicyContext, scorer, env, out):
+        """`rollout` as a generator that yields after each phase it has ENQUEUED - "step" (the env step) and "policy" (observe
+        + re-plan) - so that a caller can interleave several sub-batches on several streams (`run_pipelined`).  Results go
+        into `out` (reward, stop_time)."""
         dev, T = self.device, self.max_timesteps
         n = states["z"].shape[0]
         stopped = torch.zeros(n, dtype=torch.bool, device=dev)
         stop_time = torch.full((n,), T, dtype=torch.int64, device=dev)
         for time in range(start_time, T + 1):
-            states, done = self.env.step(states, action)
+            states, done = env.step(states, action)
             done = torch.as_tensor(done, device=dev).reshape(-1)
             stop_time = torch.where(done & ~stopped, torch.full_like(stop_time, time), stop_time)
             stopped = stopped | done
+            yield "step"
             if time == T:
                 break
             if (time - start_time) % self.sync_every == 0 and bool(stopped.all()):      # the loop's only host sync
@@ -296,7 +307,7 @@ class GreedyEvaluator:
             live = ~stopped
             x = states["x"]
             if self.use_graphs and ctx.ee is not None and x.dim() == 4 and x.dtype == torch.float32:
-                ob, emb = self._graphed_encode(x)
+                ob, emb = self._graphed_encode(x, ctx.tag)
                 self.observe(ctx, time, ob, live, rtg=pred_rtg, emb=emb)
             else:
                 self.observe(ctx, time, policy_observation(x), live, rtg=pred_rtg)
@@ -304,11 +315,12 @@ class GreedyEvaluator:
             for k in action:                                   # stopped slices keep the action that stopped them
                 action[k] = torch.where(live, new_action[k], action[k])
             pred_rtg = torch.where(live.reshape(n, 1), new_rtg, pred_rtg)
+            yield "policy"
         if scorer is not None:
-            reward = torch.as_tensor(scorer(states)).reshape(n, 1).float().cpu()
+            out["reward"] = torch.as_tensor(scorer(states)).reshape(n, 1).float().cpu()
         else:
-            reward = self.env.compute_reward(states["x"], states["gt"])
-        return reward, stop_time.cpu()
+            out["reward"] = env.compute_reward(states["x"], states["gt"])
+        out["stop_time"] = stop_time.cpu()
 
     def rollout_rows(self, states, action, pred_rtg, start_times: torch.Tensor, ctx: PolicyContext, scorer=None,
                      active: Optional[torch.Tensor] = None):
@@ -354,18 +366,95 @@ class GreedyEvaluator:
         """mat: collated `.mat` dict (x0, y0, ATy0, mask, gt); rtg [N] normalised return-to-go target;
         task [N] int task token; first_state [N, H*W]: the policy's first state token - default `mat['x0_raw']`, the
         UNclipped Re x0 the reference's datasets hand over (datasets.py:162,201), else the env's (clipped) Re x0."""
+        out: Dict[str, object] = {}
+        for _ in self._run_phases(mat, rtg, task, first_state, self.env, 0, out):
+            pass
+        return out["result"]
+
+    def _run_phases(self, mat, rtg, task, first_state, env, tag: int, out):
         dev = self.device
-        states = self.env.reset(mat, dev)
+        states = env.reset(mat, dev)
         n = states["z"].shape[0]
         if first_state is None:
             first_state = torch.as_tensor(mat["x0_raw"]) if "x0_raw" in mat else states["x"]
         if first_state.is_complex():
             first_state = first_state.real
         ctx = self.buffers(n, task)
+        ctx.tag = tag
         self.observe(ctx, 0, policy_observation(first_state.to(dev).float().reshape(n, 1, *states["z"].shape[-2:])))
         ctx.er[:, 0, 0] = rtg.reshape(n).to(dev).float()
-        initial_reward = self.env.compute_reward(states["x"], states["gt"])
+        initial_reward = env.compute_reward(states["x"], states["gt"])
         action, pred_rtg = self._initial(ctx)
-        reward, stop_time = self.rollout(states, action, pred_rtg, 1, ctx)
-        return GreedyResult(reward=reward, initial_reward=initial_reward, stop_time=stop_time,
-                            actions=ctx.ea.cpu(), x=states["x"])
+        yield "policy"
+        ro: Dict[str, torch.Tensor] = {}
+        yield from self._rollout_phases(states, action, pred_rtg, 1, ctx, None, env, ro)
+        out["result"] = GreedyResult(reward=ro["reward"], initial_reward=initial_reward, stop_time=ro["stop_time"],
+                                     actions=ctx.ea.cpu(), x=states["x"])
+
+    def run_pipelined(self, mat: Dict[str, torch.Tensor], rtg: torch.Tensor, task: torch.Tensor, parts: int = 2) -> GreedyResult:
+        """`run` with the batch cut into `parts` contiguous sub-batches that advance on their own HIP streams, half a period
+        apart: a step of the episode is a chain  env.step -> policy -> env.step ...  in which the policy's ~110 kernels of a few
+        microseconds each leave the GPU almost idle (1.2-1.4 of 9.2 ms per step at 64 x 256 x 256); with two sub-batches one's
+        policy call runs UNDER the other's env step.  Each sub-batch has its own engine replica (`PnPEnv.fork`: own workspace and
+        k-space constants), policy context and captured graphs; slices are independent (env.py:74-100), so the result is the
+        unpipelined one up to the f32 summation order of another tile plan (a sub-batch of 32 is planned unlike a batch of 64).
+        MEASURED (MI355X, 64 x 256 x 256, 30 steps, bench.py --mode greedy --pipeline 2): 9.64 ms per step against 9.39 on one
+        stream - the policy's dependent chain of small kernels stretches when each of them has to be dispatched between the other
+        sub-batch's conv workgroups (high stream priority did not change that), and two 32-slice steps cost more than one
+        64-slice step.  It is therefore OFF by default everywhere; it pays only where the policy side is a larger share."""
+        n = int(torch.as_tensor(mat["gt"]).shape[0])
+        parts = max(1, min(int(parts), n))
+        if parts == 1 or self.device.type != "cuda":
+            return self.run(mat, rtg, task)
+        dev = self.device
+        if not hasattr(self, "_forks"):
+            self._forks, self._streams = {}, {}
+        bounds = [(k * n) // parts for k in range(parts + 1)]
+        cur = torch.cuda.current_stream(dev)
+        gens, outs, streams = [], [], []
+        hw = int(torch.as_tensor(mat["gt"]).shape[-2]) * int(torch.as_tensor(mat["gt"]).shape[-1])
+        for k in range(parts):
+            a, b = bounds[k], bounds[k + 1]
+            if k not in self._forks:
+                self._forks[k] = self.env if k == 0 else self.env.fork(k)
+                # two streams per sub-batch: its env steps on a normal-priority stream, its policy calls on a HIGH-priority one -
+                # a policy kernel is a few workgroups that must not queue behind the thousands of the other sub-batch's convs
+                self._streams[k] = {"step": torch.cuda.Stream(device=dev), "policy": torch.cuda.Stream(device=dev, priority=-1)}
+            def cut(key, v):
+                v = torch.as_tensor(v)
+                if key == "mask":
+                    return v if v.numel() == hw else v.reshape(-1, *v.shape[-2:])[a:b]
+                return v[a:b] if v.dim() > 0 and v.shape[0] == n else v
+            sub = {key: cut(key, v) for key, v in mat.items()}
+            st = self._streams[k]
+            st["policy"].wait_stream(cur)
+            out: Dict[str, object] = {}
+            gens.append(self._run_phases(sub, rtg[a:b], task[a:b], None, self._forks[k], k, out))
+            outs.append(out)
+            streams.append(st)
+        # round-robin over the sub-batches, one phase each; sub-batch k starts k phases late so that steps and policy calls of
+        # different sub-batches face each other.  A sub-batch's phases alternate between its two streams; each phase first waits
+        # for the stream of the phase before it (the chain step -> policy -> step is a true dependency).
+        live = [True] * parts
+        last = ["step"] * parts                             # the phase a sub-batch enqueued last ("step": the next one is a policy phase)
+        rnd = 0
+        while any(live):
+            for k in range(parts):
+                if not live[k] or rnd < k:
+                    continue
+                nxt = "policy" if last[k] == "step" else "step"
+                streams[k][nxt].wait_stream(streams[k][last[k]])
+                with torch.cuda.stream(streams[k][nxt]):
+                    try:
+                        last[k] = next(gens[k])
+                    except StopIteration:
+                        live[k] = False
+                        last[k] = nxt
+            rnd += 1
+        for k in range(parts):
+            cur.wait_stream(streams[k]["step"])
+            cur.wait_stream(streams[k]["policy"])
+        res = [o["result"] for o in outs]
+        return GreedyResult(reward=torch.cat([r.reward for r in res]), initial_reward=torch.cat([r.initial_reward for r in res]),
+                            stop_time=torch.cat([r.stop_time for r in res]), actions=torch.cat([r.actions for r in res]),
+                            x=torch.cat([r.x for r in res]))

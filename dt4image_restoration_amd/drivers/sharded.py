@@ -39,9 +39,10 @@ def world_info(group=None) -> Tuple[int, int]:
 
 def run_sharded_greedy(evaluator: GreedyEvaluator, total: int,
                        load_shard: Callable[[int, int], Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor]],
-                       group=None, sync: Optional[Callable[[], None]] = None) -> ShardedResult:
+                       group=None, sync: Optional[Callable[[], None]] = None, pipeline: int = 1) -> ShardedResult:
     """`load_shard(start, stop)` -> (mat dict of the slices [start, stop), rtg [n], task [n]) - only this rank's shard is
-    ever materialised.  `sync()` (e.g. torch.cuda.synchronize) brackets the timed rollout."""
+    ever materialised.  `sync()` (e.g. torch.cuda.synchronize) brackets the timed rollout.  pipeline > 1: the shard advances
+    as that many sub-batches on their own streams, one's policy call under another's env step (`GreedyEvaluator.run_pipelined`)."""
     import torch.distributed as dist
     rank, world = world_info(group)
     a, b = sharding.shard_range(total, rank, world)
@@ -53,7 +54,7 @@ def run_sharded_greedy(evaluator: GreedyEvaluator, total: int,
         dist.barrier(group)
     t0 = time.perf_counter()
     if b > a:
-        res = evaluator.run(mat, rtg, task)
+        res = evaluator.run_pipelined(mat, rtg, task, pipeline) if pipeline > 1 else evaluator.run(mat, rtg, task)
         local = (res.reward.to(dev).float(), res.initial_reward.to(dev).float(), res.stop_time.to(dev))
     else:                                                 # more ranks than slices: an empty shard still joins the gather
         local = (torch.zeros((0, 1), device=dev), torch.zeros((0, 1), device=dev), torch.zeros((0,), dtype=torch.int64, device=dev))

@@ -35,16 +35,23 @@ def _as_complex(t: torch.Tensor) -> torch.Tensor:
 
 class PnPEnv:
     def __init__(self, max_episode_step: int, denoiser: UNetDenoiser2D, device_type,
-                 no_ref_scorer: Optional[Callable[[torch.Tensor], float]] = None) -> None:
+                 no_ref_scorer: Optional[Callable[[torch.Tensor], float]] = None, replica: int = 0) -> None:
         self.max_episode_step = max_episode_step
         self.denoiser = denoiser.to(device_type)
         self.no_ref_model = no_ref_scorer
         self._engine: Optional[PnPEngine] = None
+        self._device_type = device_type
+        self._replica = int(replica)
+
+    def fork(self, replica: int) -> "PnPEnv":
+        """Another env on the same denoiser weights whose engines are replicas of their own (own workspace, own k-space
+        constants): two sub-batches of one job can then be stepped concurrently on two streams."""
+        return PnPEnv(self.max_episode_step, self.denoiser, self._device_type, self.no_ref_model, replica=replica)
 
     # ---- engine management ------------------------------------------------------------------
     def _engine_for(self, n: int, h: int, w: int, device: torch.device) -> PnPEngine:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        self._engine = self.denoiser.engine_for(n, h, w, idx)
+        self._engine = self.denoiser.engine_for(n, h, w, idx, self._replica)
         return self._engine
 
     # ---- reference interface ----------------------------------------------------------------

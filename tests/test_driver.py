@@ -487,3 +487,32 @@ def test_dt_driven_episode_on_a_full_64x256_shard():
     assert r2.stop_time.tolist() == r.stop_time[sel].tolist()
     # FLOAT TOLERANCE: batch 64 and batch 2 run different tile plans (f32 summation order); 30 policy-driven steps amplify it
     assert float((r2.reward - r.reward[sel]).abs().max()) < 5e-3
+
+
+@pytest.mark.gpu
+def test_pipelined_rollout_equals_the_plain_rollout():
+    """`run_pipelined`: the batch as two sub-batches on two streams (each with its own engine replica, policy context and
+    captured graphs), one's policy call under the other's env step - the same episode, slice for slice: stop iterations equal,
+    actions and PSNR to the rounding of another tile plan (sub-batches of 3 and 4 slices are planned unlike a batch of 7).
+    Twice in a row: the second run replays the graphs captured by the first."""
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.env import PnPEnv
+    n, steps = 7, 12                                                   # ragged on purpose
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=8.0))
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    p = synthetic.make_problem(n, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=404)
+    mat = {k: torch.from_numpy(np.asarray(v)) for k, v in p.items()}
+    rtg, task = torch.full((n,), D.normalised_rtg(10.0)), torch.full((n,), 4)
+    plain = GreedyEvaluator(m, PnPEnv(steps, den, "cuda"), max_timesteps=steps, device_type="cuda", sync_every=4).run(mat, rtg, task)
+    ev = GreedyEvaluator(m, PnPEnv(steps, den, "cuda"), max_timesteps=steps, device_type="cuda", sync_every=4)
+    for _ in range(2):
+        piped = ev.run_pipelined(mat, rtg, task, parts=2)
+        torch.cuda.synchronize()
+        assert piped.stop_time.tolist() == plain.stop_time.tolist()
+        assert piped.x.shape == plain.x.shape and piped.actions.shape == plain.actions.shape
+        # FLOAT TOLERANCE: f32 summation order of another tile plan, carried through up to 12 policy-driven steps
+        assert float((piped.reward - plain.reward).abs().max()) < 2e-3
+        assert float((piped.initial_reward - plain.initial_reward).abs().max()) < 1e-4
+        np.testing.assert_allclose(piped.actions.numpy(), plain.actions.numpy(), rtol=0, atol=2e-4)
+    assert len(set(plain.stop_time.tolist())) >= 1 and float(plain.x.min()) >= 0.0
