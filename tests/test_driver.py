@@ -516,3 +516,26 @@ def test_pipelined_rollout_equals_the_plain_rollout():
         assert float((piped.initial_reward - plain.initial_reward).abs().max()) < 1e-4
         np.testing.assert_allclose(piped.actions.numpy(), plain.actions.numpy(), rtol=0, atol=2e-4)
     assert len(set(plain.stop_time.tolist())) >= 1 and float(plain.x.min()) >= 0.0
+
+
+@pytest.mark.gpu
+def test_fused_attention_equals_the_explicit_form():
+    """The GPU policy runs its causal attention as one fused kernel (F.scaled_dot_product_attention); the explicit
+    scores / mask / softmax form of the reference (decision_transformer.py:60-75) is the CPU path.  Same outputs to f32 rounding."""
+    from dt4image_restoration_amd import policy as P
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm")).cuda()
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=0.0, head_gain=12.0))
+    b, t = 5, 6
+    g = torch.Generator().manual_seed(3)
+    rtg, st = torch.rand(b, t, 1, generator=g).cuda(), torch.rand(b, t, 16384, generator=g).cuda()
+    ts, task = torch.arange(t).reshape(1, t, 1).repeat(b, 1, 1).cuda(), torch.randint(0, 9, (b, 1), generator=g).repeat(1, t).cuda()
+    act = torch.rand(b, t, 3, generator=g).cuda()
+    with torch.no_grad():
+        fused = m(rtg, st, ts, task, act)[0]
+        P.FUSED_ATTENTION = False
+        try:
+            plain = m(rtg, st, ts, task, act)[0]
+        finally:
+            P.FUSED_ATTENTION = True
+    # FLOAT TOLERANCE: the fused kernel sums the softmax in another order (f32, 18 tokens)
+    assert float((fused - plain).abs().max()) < 2e-6
