@@ -358,8 +358,9 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     constexpr int PF = WN == 2 ? 9 : 12;              // B fragments in flight in the MFMA loop (must divide 36: slots line up
                                                        // across chunks; the 16-tile upsample variant spilled 22 registers into scratch
                                                        // INSIDE its chunk loop with a ring of 9) ...
-    constexpr int KEEP = 3;                            // ... of which only the first KEEP are loaded across the chunk boundary (the
-                                                       // input transform needs the registers); the rest go out after the transform
+    constexpr int KEEP = WN == 1 ? 6 : 3;              // ... of which only the first KEEP are loaded across the chunk boundary (the
+                                                       // input transform needs the registers; the 32-channel variant's 8-byte fragments
+                                                       // leave room for 6: -1 % on the level-0 layers); the rest go out after the transform
     constexpr int PLANE = MT * CKP;                    // floats per frequency plane of V
     static_assert(SRC == SRC_PLAIN || SRC == SRC_UPCAT || SRC == SRC_FIRST, "pooled sources go through the pooled copy");
     static_assert(!FIRST || (WN == 1 && MT == 32), "fused first layer: the 32-channel variant");
