@@ -40,7 +40,7 @@ def mfma_conv_flops(n, h, w):
                    for l in unet_spec.UNET_LAYERS[1:27])
 
 
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
 
 
 def pmc_traffic(n, h, w, which):

@@ -3,7 +3,7 @@
 # stats of the same command and the three counter passes tools/refresh_profiles.py folds into profiles/.
 # Counter passes are separate runs with --kernel-trace only (no other trace domains).
 set -e -o pipefail
-TAG=${1:-r02}; N=${2:-1}
+TAG=${1:-r03}; N=${2:-1}
 R=$(pwd); G=$R/gpurun_out; mkdir -p "$G"
 python3 bench.py > "$G/bench_$TAG.json" 2> "$G/bench_$TAG.err"
 echo "bench done: $(cut -c1-120 "$G/bench_$TAG.json")"

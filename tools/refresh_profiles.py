@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 tag, pmc = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "r02"
+RND = sys.argv[3] if len(sys.argv) > 3 else "r03"
 
 shutil.copy((glob.glob(f"{G}/prof_{tag}/runc/*_kernel_stats.csv") + glob.glob(f"{G}/prof_{tag}/*kernel_stats.csv"))[0], f"{P}/{RND}_kernel_stats.csv")
 shutil.copy(f"{G}/layers_{tag}.json", f"{P}/{RND}_layers.json")
