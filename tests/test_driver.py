@@ -539,3 +539,53 @@ def test_fused_attention_equals_the_explicit_form():
             P.FUSED_ATTENTION = True
     # FLOAT TOLERANCE: the fused kernel sums the softmax in another order (f32, 18 tokens)
     assert float((fused - plain).abs().max()) < 2e-6
+
+
+def test_node_pool_grows_on_demand_and_reports_its_needs():
+    """The tree search's node storage starts small and doubles (rows kept), up to the bound of every round expanding every
+    image; past it `alloc` refuses (drivers/mcts.NodePool)."""
+    from dt4image_restoration_amd.drivers.mcts import NodePool
+    pool = NodePool(2, 4, 4, "cpu", max_capacity=7)
+    a = pool.alloc(2)
+    st = {"x": torch.arange(32.0).reshape(2, 1, 4, 4), "z": torch.ones(2, 1, 4, 4, dtype=torch.complex64),
+          "u": torch.zeros(2, 1, 4, 4, dtype=torch.complex64), "T": torch.tensor([0.1, 0.2])}
+    pool.store(a, st)
+    b = pool.alloc(3)                                      # grows: 2 -> 5 rows, the first two kept
+    assert b.tolist() == [2, 3, 4] and pool.x.shape[0] >= 5
+    assert torch.equal(pool.x[:2], st["x"].reshape(2, -1)) and torch.equal(pool.T[:2], st["T"])
+    pool.alloc(2)
+    with pytest.raises(RuntimeError, match="node pool exhausted"):
+        pool.alloc(1)
+
+
+@pytest.mark.gpu
+def test_batched_tree_search_with_one_mask_per_image():
+    """The reference reads a mask per .mat file (datasets.py:153-160): `run_batch` repeats a per-image mask [B,H,W] for the k
+    children of each image like the images themselves.  Two images with DIFFERENT masks searched at once == each searched alone."""
+    import torch.nn.functional as F
+    from dt4image_restoration_amd.denoiser import UNetDenoiser2D
+    from dt4image_restoration_amd.drivers.mcts import MCTS
+    from dt4image_restoration_amd.env import PnPEnv
+    den = UNetDenoiser2D.seeded(0, "unit_gain")
+    m = DecisionTransformer(DecisionTransformerConfig(block_size=18, n_embeds=9, mode="norm"))
+    m.load_state_dict(weights.generate_policy_weights(m, 7, t_bias=-1.0, head_gain=12.0))
+
+    def scorer(states):
+        x = states["x"]
+        return 1.0 / (1e-3 + ((x - F.avg_pool2d(x, 3, 1, 1)) ** 2).mean(dim=(1, 2, 3)))
+
+    p4 = synthetic.make_problem(1, 128, 128, accel=4.0, seed=21)
+    p8 = synthetic.make_problem(1, 128, 128, accel=8.0, seed=22, first_slice=1)
+    assert not np.array_equal(p4["mask"], p8["mask"])
+    both = {k: np.concatenate([p4[k], p8[k]], axis=0) for k in ("x0", "y0", "ATy0", "gt", "x0_raw")}
+    both["mask"] = np.stack([p4["mask"], p8["mask"]])      # [2, H, W]: one mask per image
+
+    def search(prob, n, first):
+        ev = GreedyEvaluator(m, PnPEnv(30, den, "cuda"), max_timesteps=6, device_type="cuda")
+        mat = {k: torch.from_numpy(np.asarray(v)) for k, v in prob.items()}
+        return MCTS(ev, scorer, n_children=3, rounds=3, seed=5).run_batch(mat, torch.full((n,), D.normalised_rtg(10.0)),
+                                                                         torch.full((n,), 4), first_image=first)[0]
+    together = search(both, 2, 0)
+    alone = torch.cat([search(p4, 1, 0), search(p8, 1, 1)])
+    # FLOAT TOLERANCE: batch 2 x 3 children and batch 1 x 3 run other tile plans (f32 summation order)
+    assert float((together - alone).abs().max()) < 2e-3
