@@ -266,19 +266,22 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
             const int tr = t / TC;
             const int py = STK ? 4 * (tr % (TR / 2)) : 4 * tr, px = 4 * (t % TC);
             const int gy = ty0 + py, gx = tx0 + px;                            // top-left pixel of the tile
-            const int rv = a.H - gy, cv = a.W - gx;                            // rows / columns of it inside the image
-            const unsigned base = (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4);
+            // Bounds without per-store compares: W is a multiple of 4, so a 4-wide tile is inside or outside the image as a WHOLE in
+            // x (one select per tile); its rows travel in the vector offset, so a row past H is past the descriptor's num_records
+            // (one slice) and the store is dropped by the range check; only the column step is a scalar offset.
+            const unsigned base = (gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4) : OOB;
+            const unsigned rowb = (unsigned)(a.W * a.Cout * 4);
 #pragma unroll
             for (int ay = 0; ay < 4; ++ay)
 #pragma unroll
                 for (int ax = 0; ax < 4; ++ax) {
                     const float val = e == 0 ? Y[ay][ax].x : Y[ay][ax].y;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdst,
-                                                          (ay < rv && ax < cv) ? base : OOB, (ay * a.W + ax) * a.Cout * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdst, base + ay * rowb, ax * a.Cout * 4, 0);
                 }
             if (a.pooled != nullptr) {                 // MaxPool2d(2) of the tile's four windows (noise.py:22-25)
                 const int qy = gy >> 1, qx = gx >> 1;
-                const unsigned pbase = (unsigned)(((qy * Wp + qx) * a.Cout + cout0) * 4);
+                const unsigned pbase = (qx < Wp) ? (unsigned)(((qy * Wp + qx) * a.Cout + cout0) * 4) : OOB;
+                const unsigned prowb = (unsigned)(Wp * a.Cout * 4);
 #pragma unroll
                 for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
@@ -286,8 +289,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                         const v2f mx = __builtin_elementwise_max(__builtin_elementwise_max(Y[2 * wy][2 * wx], Y[2 * wy][2 * wx + 1]),
                                                                  __builtin_elementwise_max(Y[2 * wy + 1][2 * wx], Y[2 * wy + 1][2 * wx + 1]));
                         const float val = e == 0 ? mx.x : mx.y;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool,
-                                                              (qy + wy < Hp && qx + wx < Wp) ? pbase : OOB, (wy * Wp + wx) * a.Cout * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rpool, pbase + wy * prowb, wx * a.Cout * 4, 0);
                     }
             }
         }
