@@ -600,9 +600,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float2* __restrict__ u, const float* __restrict__ sigma,
                                                          const float* __restrict__ tact, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ dst,
-                                                         int N, int H, int W, int tilesX, int tilesY) {
+                                                         int N, int H, int W, int tilesX, int tilesY, int TYG) {
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
-    constexpr int TYG = 8;                                     // tiles (of 8 rows) a workgroup walks down: the 76 weight / bias
+    // TYG (8 on chip-filling problems, fewer on small ones): tiles (of 8 rows) a workgroup walks down: the 76 weight / bias
     __shared__ float dt[2][PH][PW + 1];                        // registers of a thread are loaded once per 64 rows, and the next
     __shared__ float mt[2][PH][PW + 1];                        // tile's halo is staged (double buffer) under this tile's FMAs
     const int groupsY = (tilesY + TYG - 1) / TYG;
@@ -683,9 +683,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
                              const float* tact, const float* w, const float* bias, float* dst, int N, int H, int W,
                              hipStream_t s) {
-    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8, groupsY = (tilesY + 7) / 8;
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
+    // a workgroup walks TYG tiles down a column of tiles (weights loaded once per walk); small problems walk fewer tiles so that
+    // the grid still covers the chip (one 128 x 128 slice: 8 workgroups of 8 tiles took 27 us, 64 of one tile take a third)
+    int tyg = 8;
+    while (tyg > 1 && (long)tilesX * ((tilesY + tyg - 1) / tyg) * N < 512) tyg >>= 1;
+    const int groupsY = (tilesY + tyg - 1) / tyg;
     hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tilesX * groupsY * N)), dim3(256), 0, s, ximg, z, u, sigma, tact, w,
-                       bias, dst, N, H, W, tilesX, tilesY);
+                       bias, dst, N, H, W, tilesX, tilesY, tyg);
     return hipGetLastError();
 }
 
