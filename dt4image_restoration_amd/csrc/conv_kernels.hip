@@ -175,9 +175,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     constexpr int BN_ = WN * NT * 32;
     constexpr bool LDS_EPI = !SPLITK && (size_t)BM * (BN_ + 4) <= (size_t)PH * PW * (CK + 4);   // output tile fits in the f32 patch space
     constexpr int PATCH_FLOATS = (LDS_EPI && BM * (BN_ + 4) > PH * PW * CKP) ? BM * (BN_ + 4) : PH * PW * CKP;
-    constexpr int LDS_FLOATS = PATCH_FLOATS + (UP2 ? LH * LW * CKL : 0);
+    constexpr int LOWRES_FLOATS = UP2 ? ((LH * LW * CKL + 3) & ~3) : 0;
+    constexpr int LDS_FLOATS = PATCH_FLOATS + LOWRES_FLOATS + (UP2 ? 4 * (PH + PW) : 0);
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
     float* const lowres = patch + PATCH_FLOATS;            // UPCAT: [LH][LW][CKL] low-res source region
+    float* const rowT = lowres + LOWRES_FLOATS;            // UPCAT: per patch row / column {offsets of the two source lines in the low-res
+    float* const colT = rowT + 4 * PH;                     // region (int bits), their two weights}; zero weights outside the image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -271,29 +274,42 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKL + (idx % PPP) * 4]) = rawu[k];
         }
         __syncthreads();
+        // the interpolation's coordinates are the same for every chunk: one table entry per patch row and column (built once,
+        // below); a pixel outside the image has zero weights = the conv's zero padding
 #pragma unroll 2
         for (int k = 0; k < NIT; ++k) {
             const int idx = tid + k * 256;
             const int part = idx % PPP, pp = idx / PPP;
             const int py = pp / PWL, px = pp % PWL;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             if (idx < ITEMS) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    const float sy = a.rh * (float)gy, sx = a.rw * (float)gx;
-                    const int y0 = (int)sy, x0 = (int)sx;
-                    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-                    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
-                    const float* r0 = &lowres[((y0 - ylo) * LW - xlo) * CKL + part * 4];
-                    const float* r1 = &lowres[((y1 - ylo) * LW - xlo) * CKL + part * 4];
-                    v = f4lerp2(*reinterpret_cast<const float4*>(r0 + x0 * CKL), *reinterpret_cast<const float4*>(r0 + x1 * CKL),
-                                *reinterpret_cast<const float4*>(r1 + x0 * CKL), *reinterpret_cast<const float4*>(r1 + x1 * CKL),
-                                1.f - lx, lx, 1.f - ly, ly);
-                }
-                store_patch(py, px, part, v);
+                const float4 rt = *reinterpret_cast<const float4*>(&rowT[4 * py]), ct = *reinterpret_cast<const float4*>(&colT[4 * px]);
+                const float* l0 = &lowres[__float_as_int(rt.x) + part * 4];
+                const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
+                const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
+                store_patch(py, px, part,
+                            f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
+                                    *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
+                                    ct.z, ct.w, rt.z, rt.w));
             }
         }
     };
+    if constexpr (UP2) {
+        if (tid < PH + PW) {                               // (first read behind the barrier inside commit_lo)
+            const bool isrow = tid < PH;
+            const int pq = isrow ? tid : tid - PH;
+            const int g = (isrow ? ty0 : tx0) + pq - 1;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && g < (isrow ? a.H : a.W)) {
+                const float sc = (isrow ? a.rh : a.rw) * (float)g;
+                const int i0 = (int)sc;
+                const int i1 = i0 + (i0 < (isrow ? Hs : Ws) - 1 ? 1 : 0);
+                const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
+                const int lo = isrow ? ylo : xlo, mul = isrow ? LW * CKL : CKL;
+                e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+            }
+            *reinterpret_cast<float4*>(&(isrow ? rowT : colT)[4 * pq]) = e;
+        }
+    }
 
     if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); }
     else if (PREFETCH) issue(c_begin, 0, NIT);
