@@ -174,8 +174,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 
     constexpr int BN_ = WN * NT * 32;
     constexpr bool LDS_EPI = !SPLITK && (size_t)BM * (BN_ + 4) <= (size_t)PH * PW * (CK + 4);   // output tile fits in the f32 patch space
-    constexpr int PATCH_FLOATS = (LDS_EPI && BM * (BN_ + 4) > PH * PW * CKP) ? BM * (BN_ + 4) : PH * PW * CKP;
     constexpr int LOWRES_FLOATS = UP2 ? ((LH * LW * CKL + 3) & ~3) : 0;
+    // the output tile of the LDS epilogue may run on into the low-res region behind the patch (dead by then): with the bf16
+    // patch a 32-channel UPCAT workgroup stays under 48 KB
+    constexpr int EPI_FLOATS = LDS_EPI ? BM * (BN_ + 4) : 0;
+    constexpr int PATCH_FLOATS = PH * PW * CKP + LOWRES_FLOATS >= EPI_FLOATS ? PH * PW * CKP : EPI_FLOATS - LOWRES_FLOATS;
+    static_assert(PATCH_FLOATS % 4 == 0, "low-res region stays 16-byte aligned");
     constexpr int LDS_FLOATS = PATCH_FLOATS + LOWRES_FLOATS + (UP2 ? 4 * (PH + PW) : 0);
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
     float* const lowres = patch + PATCH_FLOATS;            // UPCAT: [LH][LW][CKL] low-res source region
@@ -220,7 +224,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 
     constexpr int LBS = NIT < 4 ? NIT : 4;               // skip-chunk pieces per synchronous batch (UPCAT)
     RawPiece<SRC> raw[UP2 ? 1 : (PREFETCH ? NIT : LB)];
-    float4 rawu[UP2 ? (NITL > LBS ? NITL : LBS) : 1];
+    // UPCAT: the low-res region of an upsampled chunk (always prefetched) or the pieces of a skip chunk - prefetched whole
+    // under the previous k-loop where the accumulator tile leaves the registers (32 accumulators), else staged in
+    // synchronous batches of LBS
+    constexpr bool SKIP_PF = UP2 && MT * NT <= 2;
+    constexpr int RAWU_SKIP = SKIP_PF ? NIT : LBS;
+    float4 rawu[UP2 ? (NITL > RAWU_SKIP ? NITL : RAWU_SKIP) : 1];
     auto issue = [&](int c, int it0, int cnt) {           // loads of pieces [it0, it0+cnt) of chunk c -> raw[0..cnt)
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     }
 
-    if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); }
+    if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); else if (SKIP_PF) issue(c_begin, 0, NIT); }
     else if (PREFETCH) issue(c_begin, 0, NIT);
 
     // LDS float offset of this lane's A row for each of its M-blocks (tap (0,0), channel 4*hh)
@@ -348,6 +357,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         if constexpr (UP2) {
             if (c >= nskip) {
                 commit_lo();
+            } else if constexpr (SKIP_PF) {
+                commit(c, 0, NIT);
             } else {
 #pragma unroll 1
                 for (int it0 = 0; it0 < NIT; it0 += LBS) { issue(c, it0, LBS); commit(c, it0, LBS); }
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
         __syncthreads();
-        if constexpr (UP2) { if (c + 1 < c_end && c + 1 >= nskip) issue_lo(c + 1); }
+        if constexpr (UP2) { if (c + 1 < c_end) { if (c + 1 >= nskip) issue_lo(c + 1); else if (SKIP_PF) issue(c + 1, 0, NIT); } }
         else if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT);
 
         const float4* bp[NT];
@@ -511,7 +522,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, bool BF16>
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
-    // (the UPCAT variant also holds the low-res source region in LDS: two workgroups per CU at most)
+    // (the UPCAT variant also holds the low-res source region in LDS and a prefetched skip chunk in registers: two
+    // workgroups per CU; three with the bf16 patch measured 8 % slower on up4.conv-0, it spills 54 registers)
     constexpr int WPS = (MT * NT <= 2 && SRC != SRC_UPCAT) ? 3 : (MT * NT <= 8 ? 2 : 1);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16>), grid, dim3(256), 0, s, a);
