@@ -139,8 +139,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK, bool BF16>
+//
+// A16 = true (bf16 mode, the 32-channel level-0 plan): the PLAIN source / the UPCAT skip tensor hold bf16 (written so by the
+// producing launch, rounded once with the same round-to-nearest-even the staging would apply - the patch gets the same
+// bits, half the HBM bytes) and so does dst unless a.act16 says f32 (the layer in front of the unfused 1x1 conv).  The
+// pooled copy and the low-res source of the upsample stay f32: their consumers round AFTER max / interpolation.
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK, bool BF16, bool A16>
 __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a) {
+    static_assert(!A16 || (BF16 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL), "bf16 activations: level-0 plan only");
     // padded pixel stride in LDS (floats): b128 lane groups hit 16 distinct slots (f32: CK + 4; bf16: CK + 8 halves)
     constexpr int CKP = BF16 ? (CK + 8) / 2 : CK + 4;
     constexpr int KCH = BF16 ? 16 : 8; // channels per k-step
@@ -155,8 +161,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     constexpr int PWL = TW + 2;        // patch width (pixels)
     constexpr int PH = TH + 2;
     constexpr int PW = PWL;            // LDS row stride (pixels)
-    constexpr int ITEMS = PH * PWL * PPP;        // 16-byte pieces per chunk
+    constexpr int ITEMS = PH * PWL * PPP;        // 16-byte f32 pieces per chunk
     constexpr int NIT = (ITEMS + 255) / 256;
+    constexpr int PPS = A16 ? CK / 8 : PPP;      // pieces per pixel / per chunk of a chunk loaded from src0 (A16: 8 bf16 channels each)
+    constexpr int ITEMS_S = PH * PWL * PPS;
+    constexpr int NIT_S = (ITEMS_S + 255) / 256;
     // PLAIN chunks: the raw loads of the next chunk are held in registers across the k-loop.  UPCAT chunks that come from
     // the bilinear x2 upsample (4 source pixels per patch pixel) do not fit in registers that way; instead the LOW-RES
     // source region of the tile, (TH/2+3) x (TW/2+3) pixels, is prefetched like a PLAIN chunk, parked in LDS, and the
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     // exists) stage synchronously in batches.
     constexpr bool UP2 = SRC == SRC_UPCAT;
     constexpr bool PREFETCH = SRC == SRC_PLAIN || UP2;
-    constexpr int LB = PREFETCH ? NIT : (NIT < 3 ? NIT : 3);   // pieces per batch when staging synchronously
+    constexpr int LB = PREFETCH ? NIT_S : (NIT < 3 ? NIT : 3);  // pieces per batch when staging synchronously
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;            // low-res region bound (rows, cols)
     constexpr int CKL = CK + 4;                                // its pixel stride (floats, always f32)
     constexpr int LITEMS = LH * LW * PPP;
@@ -222,26 +231,32 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
     const int nskip = UP2 ? a.Cskip / CK : 0;             // leading chunks that come straight from the skip tensor
 
-    constexpr int LBS = NIT < 4 ? NIT : 4;               // skip-chunk pieces per synchronous batch (UPCAT)
-    RawPiece<SRC> raw[UP2 ? 1 : (PREFETCH ? NIT : LB)];
+    constexpr int LBS = NIT_S < 4 ? NIT_S : 4;           // skip-chunk pieces per synchronous batch (UPCAT)
+    RawPiece<SRC> raw[UP2 ? 1 : (PREFETCH ? NIT_S : LB)];
     // UPCAT: the low-res region of an upsampled chunk (always prefetched) or the pieces of a skip chunk - prefetched whole
     // under the previous k-loop where the accumulator tile leaves the registers (32 accumulators), else staged in
     // synchronous batches of LBS
     constexpr bool SKIP_PF = UP2 && MT * NT <= 2;
-    constexpr int RAWU_SKIP = SKIP_PF ? NIT : LBS;
+    constexpr int RAWU_SKIP = SKIP_PF ? NIT_S : LBS;
     float4 rawu[UP2 ? (NITL > RAWU_SKIP ? NITL : RAWU_SKIP) : 1];
     auto issue = [&](int c, int it0, int cnt) {           // loads of pieces [it0, it0+cnt) of chunk c -> raw[0..cnt)
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
             const int idx = tid + (it0 + k) * 256;
-            const int part = idx % PPP, pp = idx / PPP;
+            const int part = idx % PPS, pp = idx / PPS;
             const int py = pp / PWL, px = pp % PWL;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                if constexpr (UP2)                        // a skip chunk: one plain 16-byte piece
-                    rawu[k] = *reinterpret_cast<const float4*>(a.src0 + (((size_t)n * a.H + gy) * a.W + gx) * a.Cskip + c * CK + part * 4);
-                else
+            if (idx < ITEMS_S && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+                if constexpr (A16) {                      // 8 bf16 channels of the PLAIN source / the skip tensor
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const uint16_t*>(a.src0) +
+                                                                      pix * (UP2 ? a.Cskip : a.Cin) + c * CK + part * 8);
+                    if constexpr (UP2) rawu[k] = v; else raw[k].v[0] = v;
+                } else if constexpr (UP2) {               // a skip chunk: one plain 16-byte piece
+                    rawu[k] = *reinterpret_cast<const float4*>(a.src0 + pix * a.Cskip + c * CK + part * 4);
+                } else {
                     issue_piece<SRC>(a, n, gy, gx, c * CK + part * 4, raw[k]);
+                }
             }
         }
     };
@@ -249,16 +264,18 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
             const int idx = tid + (it0 + k) * 256;
-            const int part = idx % PPP, pp = idx / PPP;
+            const int part = idx % PPS, pp = idx / PPS;
             const int py = pp / PWL, px = pp % PWL;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            if (idx < ITEMS) {
+            if (idx < ITEMS_S) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero outside the image = the conv's zero padding
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     if constexpr (UP2) v = rawu[k];
+                    else if constexpr (A16) v = raw[k].v[0];
                     else v = finish_piece<SRC>(a, gy, gx, c * CK + part * 4, raw[k]);
                 }
-                store_patch(py, px, part, v);
+                if constexpr (A16) *reinterpret_cast<float4*>(&patch[(py * PW + px) * CKP + part * 4]) = v;   // bf16 already
+                else store_patch(py, px, part, v);
             }
         }
     };
@@ -320,8 +337,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     }
 
-    if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); else if (SKIP_PF) issue(c_begin, 0, NIT); }
-    else if (PREFETCH) issue(c_begin, 0, NIT);
+    if constexpr (UP2) { if (c_begin >= nskip) issue_lo(c_begin); else if (SKIP_PF) issue(c_begin, 0, NIT_S); }
+    else if (PREFETCH) issue(c_begin, 0, NIT_S);
 
     // LDS float offset of this lane's A row for each of its M-blocks (tap (0,0), channel 4*hh)
     int aoff[MT];
@@ -358,20 +375,20 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             if (c >= nskip) {
                 commit_lo();
             } else if constexpr (SKIP_PF) {
-                commit(c, 0, NIT);
+                commit(c, 0, NIT_S);
             } else {
 #pragma unroll 1
-                for (int it0 = 0; it0 < NIT; it0 += LBS) { issue(c, it0, LBS); commit(c, it0, LBS); }
+                for (int it0 = 0; it0 < NIT_S; it0 += LBS) { issue(c, it0, LBS); commit(c, it0, LBS); }
             }
         } else if (PREFETCH) {
-            commit(c, 0, NIT);
+            commit(c, 0, NIT_S);
         } else {
 #pragma unroll 1
             for (int it0 = 0; it0 < NIT; it0 += LB) { issue(c, it0, LB); commit(c, it0, LB); }
         }
         __syncthreads();
-        if constexpr (UP2) { if (c + 1 < c_end) { if (c + 1 >= nskip) issue_lo(c + 1); else if (SKIP_PF) issue(c + 1, 0, NIT); } }
-        else if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT);
+        if constexpr (UP2) { if (c + 1 < c_end) { if (c + 1 >= nskip) issue_lo(c + 1); else if (SKIP_PF) issue(c + 1, 0, NIT_S); } }
+        else if (PREFETCH && c + 1 < c_end) issue(c + 1, 0, NIT_S);
 
         const float4* bp[NT];
 #pragma unroll
@@ -456,13 +473,32 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
                 return;
             }
         }
+        if (A16 && (a.act16 & 2)) {                        // dst holds bf16: 8 channels (16 B) per lane, 64 B per pixel
+            uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
 #pragma unroll 4
-        for (int f = tid; f < BM * V4; f += 256) {
-            const int p = f / V4, c4 = f % V4;
-            const int gy = ty0 + p / TW, gx = tx0 + p % TW;
-            if (gy < a.H && gx < a.W)
-                *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cbase + 4 * c4) =
-                    *reinterpret_cast<const float4*>(&patch[p * OSTR + 4 * c4]);
+            for (int f = tid; f < BM * (BN / 8); f += 256) {
+                const int p = f / (BN / 8), c8 = f % (BN / 8);
+                const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+                if (gy < a.H && gx < a.W) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(&patch[p * OSTR + 8 * c8]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&patch[p * OSTR + 8 * c8 + 4]);
+                    uint4 o;
+                    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.x, v0.y}, bf16x2));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.z, v0.w}, bf16x2));
+                    o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.x, v1.y}, bf16x2));
+                    o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.z, v1.w}, bf16x2));
+                    *reinterpret_cast<uint4*>(d16 + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cbase + 8 * c8) = o;
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int f = tid; f < BM * V4; f += 256) {
+                const int p = f / V4, c4 = f % V4;
+                const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+                if (gy < a.H && gx < a.W)
+                    *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cbase + 4 * c4) =
+                        *reinterpret_cast<const float4*>(&patch[p * OSTR + 4 * c4]);
+            }
         }
         if (a.pooled != nullptr) {                         // MaxPool2d(2) of this tile for the next stage
             const int Hp = a.H >> 1, Wp = a.W >> 1;
@@ -526,7 +562,15 @@ static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t 
     // workgroups per CU; three with the bf16 patch measured 8 % slower on up4.conv-0, it spills 54 registers)
     constexpr int WPS = (MT * NT <= 2 && SRC != SRC_UPCAT) ? 3 : (MT * NT <= 8 ? 2 : 1);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16>), grid, dim3(256), 0, s, a);
+    constexpr bool CAN16 = BF16 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL;
+    if constexpr (CAN16) {
+        if (a.act16 & 1) {
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16, true>), grid, dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    if (a.act16 != 0) return hipErrorInvalidValue;        // bf16 activations reach only the plan that has them
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -601,6 +645,7 @@ Tuning tuning_from_env() {
     t.no_f4_fused_first = getenv("PNP_NO_F4_FUSED_FIRST") != nullptr;
     if (const char* v = getenv("PNP_WINO_F4_MT16")) t.f4_mt16 = atoi(v);
     if (const char* v = getenv("PNP_WINO_F4_ORDER")) t.f4_order = atoi(v) != 0;
+    t.bf16_f32_acts = getenv("PNP_BF16_F32_ACTS") != nullptr;
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;
 }
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float2* __restrict__ u, const float* __restrict__ sigma,
                                                          const float* __restrict__ tact, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ dst,
-                                                         int N, int H, int W, int tilesX, int tilesY, int TYG) {
+                                                         int N, int H, int W, int tilesX, int tilesY, int TYG, int dst16) {
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
     // TYG (8 on chip-filling problems, fewer on small ones): tiles (of 8 rows) a workgroup walks down: the 76 weight / bias
     __shared__ float dt[2][PH][PW + 1];                        // registers of a thread are loaded once per 64 rows, and the next
@@ -702,7 +747,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                 o.y = fmaxf(acc[1], kLeaky * acc[1]);
                 o.z = fmaxf(acc[2], kLeaky * acc[2]);
                 o.w = fmaxf(acc[3], kLeaky * acc[3]);
-                *reinterpret_cast<float4*>(dst + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o;
+                if (dst16) {                                  // bf16 activations (see conv3x3_mfma_kernel, A16)
+                    uint2 o16;
+                    o16.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o.x, o.y}, bf16x2));
+                    o16.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o.z, o.w}, bf16x2));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o16;
+                } else {
+                    *reinterpret_cast<float4*>(dst + (((size_t)n * H + gy) * W + gx) * 32 + cg * 4) = o;
+                }
             }
         }
     }
@@ -710,7 +762,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 
 hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
                              const float* tact, const float* w, const float* bias, float* dst, int N, int H, int W,
-                             hipStream_t s) {
+                             hipStream_t s, bool dst_bf16) {
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
     // a workgroup walks TYG tiles down a column of tiles (weights loaded once per walk); small problems walk fewer tiles so that
     // the grid still covers the chip (one 128 x 128 slice: 8 workgroups of 8 tiles took 27 us, 64 of one tile take a third)
@@ -718,7 +770,7 @@ hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u
     while (tyg > 1 && (long)tilesX * ((tilesY + tyg - 1) / tyg) * N < 512) tyg >>= 1;
     const int groupsY = (tilesY + tyg - 1) / tyg;
     hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tilesX * groupsY * N)), dim3(256), 0, s, ximg, z, u, sigma, tact, w,
-                       bias, dst, N, H, W, tilesX, tilesY, tyg);
+                       bias, dst, N, H, W, tilesX, tilesY, tyg, dst_bf16 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -91,6 +91,7 @@ struct pnp_engine {
     bool fuse_last = false;           // last 1x1 layer rides in the epilogue of up4.conv-2
     bool fuse_first = false;          // first layer (2 -> 32) is computed in the staging of inc.conv-1 (F(4x4) 32-channel variant)
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
+    bool act16 = false;               // bf16 mode: the 32-channel level-0 activations (lv[0].p/q/s) are stored as bf16 (ConvArgs.act16)
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
@@ -161,7 +162,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         return fail(PNP_ERR_STATE, "this handle was created with PNP_FLAG_NO_DENOISER");
     if (!e->fuse_first) {
         Prof p(e, s, 1, 0);
-        HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s));
+        HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s, e->act16));
     }
     const bool per_layer = (e->cfg.flags & PNP_FLAG_PROFILE_LAYERS) != 0;
     Prof run(e, s, 0, -1, !per_layer, true);              // one event pair around the whole conv3x3 run
@@ -173,6 +174,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         a.pooled = pooled;
         a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
         a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
+        if (e->act16 && lvl == 0) a.act16 = li == 26 ? 1 : 3;     // level 0 reads and writes bf16; the unfused 1x1 conv reads f32
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
             const int hs = a.H / 2, ws = a.W / 2;
@@ -221,6 +223,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         ConvArgs a{};
         a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
         a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
+        a.act16 = e->act16 ? 1 : 0;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
         {
@@ -342,6 +345,11 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
         }
         e->fuse_last = !(cfg->flags & PNP_FLAG_KEEP_STAGES) && (e->wino[26] || conv3x3_pooled_output_ok(e->cplan[26]));
         e->fuse_first = e->wino[1] && e->wplan[1].algo == 4 && e->wplan[1].bn == 32 && e->wplan[1].mt == 32 && !e->tune.no_f4_fused_first;
+        // bf16 mode: the five 32-channel level-0 layers exchange bf16 tensors (same bits the staging would round to; half the
+        // bytes of the HBM-bound level).  Needs the plan that has the variant on all five and the pooled copy for down1
+        // (always so today); a KEEP_STAGES handle keeps f32 stages for pnp_unet_read_stage.
+        e->act16 = bf16 && !(cfg->flags & PNP_FLAG_KEEP_STAGES) && !e->tune.bf16_f32_acts && e->pool_ok[0];
+        for (int li : {1, 2, 24, 25, 26}) e->act16 = e->act16 && conv3x3_pooled_output_ok(e->cplan[li]);
     }
     const size_t cbytes = N * H * W * sizeof(float2);
     if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||
@@ -606,6 +614,7 @@ int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, in
     PNP_API_BEGIN
     if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
     if (which == 8 && e->fuse_last) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 8 is fused away; create the handle with PNP_FLAG_KEEP_STAGES");
+    if (which == 0 && e->act16) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 0 is held as bf16 on this handle; create it with PNP_FLAG_KEEP_STAGES");
     PNP_ON_DEVICE(e);
     // stage outputs: inc, down1..4 live in lv[k].s; up1..4 in lv[3..0].p
     const int lvl = which <= 4 ? which : 8 - which;

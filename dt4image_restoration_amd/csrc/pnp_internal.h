@@ -23,6 +23,7 @@ struct Tuning {
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
     int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
                                   // 64-channel-block layer on 16-tile M-blocks
+    bool bf16_f32_acts = false;   // PNP_BF16_F32_ACTS (ablation): bf16 mode keeps every activation in f32, as rounds 1-2 did
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
@@ -64,6 +65,7 @@ struct ConvArgs {
     int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
     int bf16;            // direct kernel: bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate
+    int act16;           // bf16 mode, 32-channel plan: bit 0 = src0 (PLAIN source / UPCAT skip) holds bf16, 2 B per channel; bit 1 = dst too
     int order;           // F(4x4): blockIdx -> tile order (wino4_decode), from the plan
 #ifdef PNP_STAMPS
     int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
@@ -116,7 +118,7 @@ hipError_t launch_conv3x3_winograd(const ConvArgs& a, const WinoPlan& p, int src
 // is the image channel.
 hipError_t launch_conv_first(const float* ximg, const float2* z, const float2* u, const float* sigma,
                              const float* tact, const float* w, const float* bias, float* dst,
-                             int N, int H, int W, hipStream_t s);
+                             int N, int H, int W, hipStream_t s, bool dst_bf16 = false);
 hipError_t launch_conv_last(const float* act, const float* ximg, const float2* z, const float2* u,
                             const float* tact, const float* w, const float* bias, float* out,
                             int N, int H, int W, hipStream_t s);

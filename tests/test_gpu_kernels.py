@@ -267,6 +267,29 @@ def test_bf16_convs_trajectory_psnr_offsets(sd_np):
         assert float((p - O.psnr(sf["x"], sf["gt"]).reshape(-1)).abs().max()) < 0.01
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 128, 128), (3, 48, 80), (1, 256, 256)])
+def test_bf16_activation_storage_is_bit_neutral(sd_np, n, h, w, monkeypatch):
+    """bf16 mode keeps the 32-channel level-0 activations in HBM as bf16 (ConvArgs.act16): the producer rounds once with the
+    rounding the consumer's staging would apply, so the denoiser output must equal - bit for bit - the output of a handle
+    that keeps those tensors in f32 (PNP_BF16_F32_ACTS, the layout of rounds 1-2).  Stage 0 of such a handle is not readable
+    as f32 and says so."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    x = ((torch.from_numpy(synthetic.hash_uniform(5, h * 1000 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
+    sigma = (torch.linspace(5, 50, n) / 255.0).cuda()
+    e16 = PnPEngine(n, h, w, bf16_convs=True)
+    e16.load_weights(sd_np)
+    monkeypatch.setenv("PNP_BF16_F32_ACTS", "1")
+    e32 = PnPEngine(n, h, w, bf16_convs=True)
+    e32.load_weights(sd_np)
+    monkeypatch.delenv("PNP_BF16_F32_ACTS")
+    a, b = e16.denoise(x, sigma), e32.denoise(x, sigma)
+    assert torch.equal(a, b)
+    assert float((a - x).abs().max()) > 1e-3                       # the network did something
+    e32.read_stage(0)
+    with pytest.raises(RuntimeError, match="bf16"):
+        e16.read_stage(0)
+
+
 # ---- shape sweep: every tile-width variant, ragged tile grids, every batch remainder ---------------------------------------
 _SWEEP = [(1, 16, 48), (5, 32, 16), (2, 80, 48), (3, 96, 112), (1, 144, 64), (4, 16, 16), (2, 64, 176), (1, 208, 32)]
 
