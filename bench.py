@@ -276,7 +276,8 @@ def main():
         exec_step = n * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * ratio.get(algos[l.index], 1.0)
                             for l in unet_spec.UNET_LAYERS[1:27])
         executed = exec_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
-        conv_traffic, conv_traffic_src = pmc_traffic(n, h, w, "conv")
+        # the PMC traffic files are passes of the default (f32) command: no figure for the bf16-operand mode
+        conv_traffic, conv_traffic_src = (None, None) if bf16 else pmc_traffic(n, h, w, "conv")
         ms_all = sorted(1e3 * t / steps for t in times)
         out = {
             "metric": "pnp_admm_iterations_per_sec", "value": round(value, 4), "unit": "batch-iterations/s",
@@ -294,9 +295,10 @@ def main():
             "slice_iterations_per_sec": round(value * n, 2),
             "psnr_mean_db": round(float(psnr_all.mean()), 4),
             "roofline": {
-                "kernel": "conv3x3_wino4_kernel + conv3x3_wino4p_kernel + conv3x3_winograd_kernel + conv3x3_mfma_kernel (26 launches/step: all denoiser conv3x3 layers "
-                          f"with Cin>=32; {sum(1 for v in algos if v == 4)} on Winograd F(4x4,3x3), {sum(1 for v in algos if v == 1)} "
-                          f"on Winograd F(2x2,3x3), {sum(1 for v in algos if v == 0)} direct)",
+                "kernel": "conv3x3_wino4_kernel + conv3x3_wino4p_kernel + conv3x3_winograd_kernel + conv3x3_mfma_kernel + conv3x3_bf16ws_kernel "
+                          f"(26 launches/step: all denoiser conv3x3 layers with Cin>=32; {sum(1 for v in algos if v == 4)} on Winograd F(4x4,3x3), "
+                          f"{sum(1 for v in algos if v == 1)} on Winograd F(2x2,3x3), {sum(1 for v in algos[1:27] if v == 0)} direct, "
+                          f"{sum(1 for v in algos if v == 5)} bf16 producer/consumer)",
                 "bound": "mfma", "achieved": round(executed, 3) if executed else None, "peak": mfma_peak,
                 "unit": "TFLOP/s", "frac": round(executed / mfma_peak, 4) if executed else None,
                 "traffic": conv_traffic, "traffic_source": conv_traffic_src,

@@ -1,0 +1,446 @@
+// bf16-operand conv3x3 for gfx950, producer / consumer form (PNP_FLAG_BF16_CONVS, BASELINE configs[4]; the layers with
+// Cout >= 64 on chip-filling problems).  Same arithmetic as conv3x3_mfma_kernel<.., BF16 = true> (conv_kernels.hip): operands
+// rounded to bf16 (round to nearest even), v_mfma_f32_32x32x16_bf16 with f32 accumulate, f32 bias / LeakyReLU / activations
+// (/root/reference/evaluation/noise.py:88-98 ConvBlock; :22-25 MaxPool2d when the source is pooled while staging).
+//
+// Why another kernel: a bf16 k-step of the 4 x 2 register tile is 8 MFMAs = 256 cycles, sixteen times shorter than the f32
+// one, and the all-waves-do-everything schedule of conv_kernels.hip stops working at that rate (measured, r03: MFMA pipe
+// busy 0.15-0.26, WAIT_ANY 0.5-0.6):
+//   * vector-memory loads return IN ORDER per wave, so a weight-fragment load issued behind the next chunk's patch loads
+//     (HBM, microseconds) waits for them however deep the fragment ring is;
+//   * patch registers + 128 accumulators + a ring deep enough for L2 latency do not fit 256 VGPRs (61-73 spilled).
+// Here a workgroup is 8 waves, two per SIMD: waves 0-3 (consumers) only run the k-loop - accumulators, A fragments from LDS,
+// a 6-deep ring of weight fragments whose loads have nothing slow in front of them - and the epilogue; waves 4-7 (producers)
+// only fetch, transform and round the next chunk's patch into the other half of a double-buffered LDS patch.  One
+// workgroup barrier per chunk hands a buffer over in each direction:
+//     interval k :  consumers  k-loop(item k-1) from buffer (k-1)&1
+//                   producers  wait loads(k) - write buffer k&1 - issue loads(k+1)
+//     barrier #k :  buffer k&1 is complete; buffer (k-1)&1 is free
+// An "item" is one (tile, 32-channel chunk); a workgroup walks tiles blockIdx.x, + gridDim.x, ... (persistent, one per CU),
+// so the producers are already fetching the next tile while the consumers store this one.
+#include "pnp_internal.h"
+#include "conv_staging.h"
+// Diagnostic build (-DPNP_WS_STAMPS, `make stamps`; tools/ws_stamps.py): s_memtime of consumer wave 0 and producer wave 4 of one
+// workgroup at every hand-over, per launch.
+#ifdef PNP_WS_STAMPS
+__device__ unsigned long long g_ws_stamps[64 * 2 * 128];
+static int g_ws_slot = 0;
+#define WS_STAMP(role) do { if (blockIdx.x == 17 && lane == 0 && (wid == 0 || wid == 4) && nst < 128) { g_ws_stamps[(a.order * 2 + (role)) * 128 + nst] = __builtin_amdgcn_s_memtime(); } ++nst; } while (0)
+#else
+#define WS_STAMP(role) do { } while (0)
+#endif
+
+namespace pnp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS floats of a workgroup: two patches of (TH+2) x (TW+2) pixels x 80 B; UPCAT adds the f32 low-res source region of one
+// upsampled chunk ((TH/2+3) x (TW/2+3) pixels x 36 floats) and two copies (tile parity) of the interpolation table.
+template <int TW, int WM, int SRC>
+constexpr int bf16ws_lds_floats() {
+    constexpr int TH = WM * 128 / TW, PH = TH + 2, PW = TW + 2;
+    return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0);
+}
+
+template <int TW, int WM, int WN, int SRC>
+__global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
+    constexpr int MT = 4, NT = 2, CK = 32;
+    constexpr int KS = 9 * (CK / 16);   // k-steps (16 channels) per chunk
+    constexpr int PFD = 6;              // weight fragments in flight, k-steps ahead (divides KS: k-step j sits in slot j % PFD)
+    static_assert(KS % PFD == 0 && WM * WN == 4, "ring / wave grid");
+    constexpr int CKP = (CK + 8) / 2;   // patch pixel stride in floats (CK + 8 halves: b128 lane groups on distinct banks)
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int TH = BM / TW, PH = TH + 2, PW = TW + 2;
+    constexpr int PPP = CK / 4;         // 16-byte f32 pieces per pixel
+    constexpr int ITEMS = PH * PW * PPP;
+    constexpr int NIT = (ITEMS + 255) / 256;
+    constexpr int PATCH = PH * PW * CKP;
+    constexpr int NRAW = SRC == SRC_POOL ? 4 : 1;
+    static_assert(SRC == SRC_PLAIN || SRC == SRC_POOL || SRC == SRC_UPCAT, "sources staged by this kernel");
+    constexpr bool UP2 = SRC == SRC_UPCAT;
+    // UPCAT (noise.py:39,46,59): chunks < nskip come straight from the skip tensor; the others are the bilinear x2 upsample
+    // (align_corners=True) of the low-res tensor: the producers park the chunk's low-res region [ylo, ylo+LH) x [xlo, xlo+LW)
+    // in LDS (f32), meet at an extra workgroup barrier X - the consumers pass it early in the k-loop of the item before - and
+    // interpolate the patch LDS -> LDS in f32 before rounding, exactly as conv_kernels.hip does
+    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3, CKL = CK + 4;
+    constexpr int NITL = (LH * LW * PPP + 255) / 256;
+    constexpr int XK = 2;               // the consumers' k-step in front of which barrier X sits
+    static_assert(NITL <= NIT, "a raw set holds either kind of item");
+    static_assert(PPP == 8, "256 producer lanes = 32 pixels x 8 pieces per pass");
+    extern __shared__ __attribute__((aligned(16))) float patch[];   // bf16ws_lds_floats(): 54-130 KB, dynamic
+    float* const lowres = patch + 2 * PATCH;                        // UPCAT: [LH * LW][CKL]
+    float* const tabs = lowres + LH * LW * CKL;                     // UPCAT: [2][PH + PW] x {offset of source line 0, 1; weight 0, 1}
+    const int nskip = UP2 ? a.Cskip / CK : 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = a.tilesX * a.tilesY * a.N;
+    const int total = tilesM * (a.Cout / BN);
+    const int nchunks = a.Cin / CK;
+    // tile t: output-channel block cb = t / tilesM is the slow index, so the chip streams one block's weights at a time
+    auto slice_of = [&](int t) { return (t % tilesM) / (a.tilesX * a.tilesY); };
+    auto next_live = [&](int t) {       // first tile >= t (stride gridDim.x) whose slice is still running
+        while (t < total && a.tact != nullptr && a.tact[slice_of(t)] > 0.5f) t += (int)gridDim.x;
+        return t;
+    };
+#ifdef PNP_WS_STAMPS
+    int nst = 0;
+#endif
+    WS_STAMP(wid >= 4);
+    int t = next_live((int)blockIdx.x);
+    if (t >= total) return;             // (both roles agree: no barrier is ever reached)
+    WS_STAMP(wid >= 4);
+
+    if (wid >= 4) {
+        // ---------------------------------------------------------------- producers ----------------------------
+        // Staging has to be cheap in INSTRUCTIONS: a chunk's k-loop is only 4608 MFMA cycles, and NIT pieces per lane with
+        // div / mod / 64-bit address arithmetic each (what conv_kernels.hip does, amortised there over a 16x longer k-loop)
+        // cost more vector issue than that.  A lane's pieces are pixel p0 + 32 k (k = 0..NIT-1), part tid % 8 - so the
+        // patch coordinates (once per kernel), the byte offset of each piece in its slice with 0x80000000 for "outside the
+        // image" (once per tile; the buffer load's range check then returns the conv's zero padding) and LDS addresses that
+        // differ by constants are all the state; per chunk a piece costs one buffer load, two converts and one LDS store.
+        const int ptid = tid - 256;
+        const int part = ptid % PPP, p0 = ptid / PPP;
+        constexpr int SRCMUL = SRC == SRC_POOL ? 2 : 1;        // POOL: the source is 2H x 2W (noise.py:22-25 MaxPool2d(2))
+        const int Hs = SRCMUL * a.H, Ws = SRCMUL * a.W;
+        int pyx[NIT];                                          // (py << 16) | px of piece k's patch pixel; -1: no such piece
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int pp = p0 + 32 * k;
+            pyx[k] = pp < PH * PW ? (((pp / PW) << 16) | (pp % PW)) : -1;
+        }
+        int lyx[UP2 ? NITL : 1];                               // same for the low-res region's pieces
+        if constexpr (UP2) {
+#pragma unroll
+            for (int k = 0; k < NITL; ++k) {
+                const int lp = p0 + 32 * k;
+                lyx[k] = lp < LH * LW ? (((lp / LW) << 16) | (lp % LW)) : -1;
+            }
+        }
+        unsigned goff[NIT];
+        unsigned goffL[UP2 ? NITL : 1];
+        __amdgpu_buffer_rsrc_t rsrcL;
+        int tile_par = 1;                                      // parity of the tile decoded last (UPCAT tables)
+        typedef float4 RawSet[NIT][NRAW];
+        RawSet raw0, raw1;                                     // items alternate between the two sets: two items' loads in flight (PLAIN)
+        __amdgpu_buffer_rsrc_t rsrc;
+        auto decode = [&](int tt) {
+            const int m = tt % tilesM;
+            const int tx0 = (m % a.tilesX) * TW, ty0 = ((m / a.tilesX) % a.tilesY) * TH, n = m / (a.tilesX * a.tilesY);
+            const int C0 = UP2 ? a.Cskip : a.Cin;                  // channels of the tensor behind src0
+            const size_t slice = (size_t)Hs * Ws * C0;
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * slice), 0, (int)(slice * sizeof(float)), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int gy = ty0 + (pyx[k] >> 16) - 1, gx = tx0 + (pyx[k] & 0xffff) - 1;
+                const bool in = pyx[k] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                goff[k] = in ? (unsigned)(((SRCMUL * gy) * Ws + SRCMUL * gx) * C0 + part * 4) * 4u : 0x80000000u;
+            }
+            if constexpr (UP2) {
+                const int Hl = a.H >> 1, Wl = a.W >> 1, Cup = a.Cin - a.Cskip;
+                const int ylo = (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)), xlo = (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0));
+                const size_t sl = (size_t)Hl * Wl * Cup;
+                rsrcL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 + (size_t)n * sl), 0, (int)(sl * sizeof(float)), 0x00020000);
+#pragma unroll
+                for (int k = 0; k < NITL; ++k) {
+                    const int sy = ylo + (lyx[k] >> 16), sx = xlo + (lyx[k] & 0xffff);
+                    goffL[k] = (lyx[k] >= 0 && sy < Hl && sx < Wl) ? (unsigned)((sy * Wl + sx) * Cup + part * 4) * 4u : 0x80000000u;
+                }
+                // this tile's interpolation table (ATen upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1),
+                // weights (1-l, l)); a row / column outside the image gets zero weights on line 0 = the conv's zero padding.
+                // Copy tile_par: its previous user is two tiles back, every item of which is committed (>= 3 chunks per tile)
+                tile_par ^= 1;
+                if (ptid < PH + PW) {
+                    const bool isrow = ptid < PH;
+                    const int pq = isrow ? ptid : ptid - PH;
+                    const int gq = (isrow ? ty0 : tx0) + pq - 1;
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gq >= 0 && gq < (isrow ? a.H : a.W)) {
+                        const float sc = (isrow ? a.rh : a.rw) * (float)gq;
+                        const int i0 = (int)sc;
+                        const int i1 = i0 + (i0 < (isrow ? Hl : Wl) - 1 ? 1 : 0);
+                        const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
+                        const int lo = isrow ? ylo : xlo, mul = isrow ? LW * CKL : CKL;
+                        e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+                    }
+                    *reinterpret_cast<float4*>(&tabs[tile_par * 4 * (PH + PW) + 4 * ptid]) = e;
+                }
+            }
+        };
+        auto issue = [&](int c, RawSet& raw) {
+            if constexpr (UP2) {
+                if (c >= nskip) {                              // the low-res region of an upsampled chunk
+                    const int sol = (c - nskip) * CK * 4;
+#pragma unroll
+                    for (int k = 0; k < NITL; ++k) raw[k][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, goffL[k], sol, 0));
+                    return;
+                }
+            }
+            const int so = c * CK * 4;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                raw[k][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so, 0));
+                if constexpr (SRC == SRC_POOL) {
+                    raw[k][NRAW > 1 ? 1 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + a.Cin * 4, 0));
+                    raw[k][NRAW > 1 ? 2 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + Ws * a.Cin * 4, 0));
+                    raw[k][NRAW > 1 ? 3 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + (Ws + 1) * a.Cin * 4, 0));
+                }
+            }
+        };
+        auto store_bf16 = [&](float* buf, int k, float4 v) {
+            const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);   // round to nearest even
+            const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+            *reinterpret_cast<uint2*>(&buf[(p0 + 32 * k) * CKP + part * 2]) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+        };
+        auto commit = [&](float* buf, const RawSet& raw, int meta) {   // meta (UPCAT): bit 0 = upsampled chunk, bit 1 = its tile's parity
+            if constexpr (UP2) {
+                if (meta & 1) {
+#pragma unroll
+                    for (int k = 0; k < NITL; ++k)
+                        if (p0 + 32 * k < LH * LW) *reinterpret_cast<float4*>(&lowres[(p0 + 32 * k) * CKL + part * 4]) = raw[k][0];
+                    __syncthreads();                           // barrier X: the region is parked (its readers are these four waves)
+                    const float* tb = tabs + (meta >> 1) * 4 * (PH + PW);
+#pragma unroll 2
+                    for (int k = 0; k < NIT; ++k) {
+                        if (p0 + 32 * k < PH * PW) {
+                            const float4 rt = *reinterpret_cast<const float4*>(&tb[4 * (pyx[k] >> 16)]);
+                            const float4 ct = *reinterpret_cast<const float4*>(&tb[4 * (PH + (pyx[k] & 0xffff))]);
+                            const float* l0 = &lowres[__float_as_int(rt.x) + part * 4];
+                            const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
+                            const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
+                            store_bf16(buf, k, f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
+                                                       *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
+                                                       ct.z, ct.w, rt.z, rt.w));
+                        }
+                    }
+                    return;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                if (p0 + 32 * k < PH * PW) {                     // (out-of-image pieces loaded zeros: the conv's zero padding)
+                    float4 v = raw[k][0];
+                    if constexpr (SRC == SRC_POOL)
+                        v = f4max(f4max(raw[k][0], raw[k][NRAW > 1 ? 1 : 0]), f4max(raw[k][NRAW > 1 ? 2 : 0], raw[k][NRAW > 1 ? 3 : 0]));
+                    store_bf16(buf, k, v);
+                }
+            }
+        };
+        // The producers run TWO items ahead of the consumers: item g is committed from raw set g & 1 into patch buffer g & 1,
+        // and the loads of item g + 2 go out into the freed set right away - a whole k-loop interval before they are needed.
+        int c = 0;                                             // (t, c): the item issued last
+        int pending = 0;                                       // items issued, not yet committed
+        bool dry = false;                                      // no further item to issue
+        auto issue_next = [&](RawSet& raw, int& meta, bool first) {
+            if (dry) return;
+            int t1 = t, c1 = c + 1;
+            if (first) { c1 = 0; }
+            else if (c1 == nchunks) { c1 = 0; t1 = next_live(t + (int)gridDim.x); }
+            if (t1 >= total) { dry = true; return; }
+            if (first || t1 != t) decode(t1);
+            issue(c1, raw);
+            meta = (c1 >= nskip && UP2 ? 1 : 0) | (tile_par << 1);
+            t = t1; c = c1; ++pending;
+        };
+        int meta0 = 0, meta1 = 0;
+        auto step = [&](RawSet& raw, int& meta, float* buf) {
+            commit(buf, raw, meta);
+            WS_STAMP(1);
+            --pending;
+            issue_next(raw, meta, false);
+            WS_STAMP(1);
+            __syncthreads();                                   // barrier #g
+            WS_STAMP(1);
+            return pending > 0;
+        };
+        issue_next(raw0, meta0, true);
+        WS_STAMP(1);
+        if constexpr (NRAW == 1 && !(UP2 && NIT > 12)) {
+            issue_next(raw1, meta1, false);
+            for (;;) {
+                if (!step(raw0, meta0, patch)) break;
+                if (!step(raw1, meta1, patch + PATCH)) break;
+            }
+        } else {                                               // POOL (four loads per piece), UPCAT on the 512-pixel tile: one item ahead (registers)
+            for (;;) {
+                if (!step(raw0, meta0, patch)) break;
+                if (!step(raw0, meta0, patch + PATCH)) break;
+            }
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers ----------------------------
+    const int wm = wid / WN, wn = wid % WN;
+    const int hh = lane >> 5, li = lane & 31;
+    int aoff[MT];                       // LDS float offset of this lane's A row per M-block (tap (0,0), k-half hh)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = (wm * MT + mt) * 32 + li;
+        aoff[mt] = ((q / TW) * PW + (q % TW)) * CKP + 4 * hh;
+    }
+    const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * sizeof(float)), 0x00020000);
+    // What a tile needs from memory besides its patches is requested ahead, so that a tile boundary costs the consumers no
+    // round trip: the next live tile (a tact[] read) at the start of this one, its bias values and the first PFD k-steps
+    // of its weights right after this tile's last k-loop - they land under the epilogue's stores.  (The ring's refills of a
+    // tile's last PFD k-steps run on past its weights and are thrown away: keeping the chunk loop free of a "last chunk"
+    // case is what keeps it free of spills - hipcc unswitches the 144-MFMA body on it and then runs out of registers.)
+    // Weight fragments come through a buffer descriptor: the lane part of the address (lane * 16 B) is one VGPR for good and
+    // everything else - tile, N-block, chunk, k-step - is scalar arithmetic in the instruction's soffset.
+    const size_t wbytes = ((size_t)(a.Cout / 32) * nchunks * KS + 16) * 1024;      // the pack ends in 16 zero k-steps
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, (int)wbytes, 0x00020000);
+    const int wlane = lane * 16;
+    const int wstride = nchunks * KS * 1024;                                       // bytes between N-blocks
+    auto wbase = [&](int tt) {          // byte offset of the weight stream of tile tt, this wave's N-block 0
+        return ((tt / tilesM) * (WN * NT) + wn * NT) * wstride;
+    };
+    auto wload = [&](int soff) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, soff, 0)); };
+    float4 bq[PFD][NT];
+    float bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bias_v[nt] = a.bias[((t / tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
+#pragma unroll
+        for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wbase(t) + nt * wstride + p * 1024);
+    }
+    int g = 0;
+    WS_STAMP(0);
+    while (t < total) {
+        const int cbt = t / tilesM, m = t % tilesM;
+        const int tx0 = (m % a.tilesX) * TW, ty0 = ((m / a.tilesX) % a.tilesY) * TH, n = m / (a.tilesX * a.tilesY);
+        const int t_next = next_live(t + (int)gridDim.x);      // (its loads fly under this tile's k-loops)
+        const int wtile = wbase(t);
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bias_v[nt];   // accumulators start at the bias
+        }
+
+        for (int c = 0; c < nchunks; ++c, ++g) {
+            WS_STAMP(0);
+            __syncthreads();                                   // barrier #g: this item's patch is complete
+            WS_STAMP(0);
+            const bool park = UP2 && c + 1 < nchunks && c + 1 >= nskip;   // the producers park a low-res region during this k-loop
+            const float* pb = patch + (g & 1) * PATCH;
+            const int wc = wtile + c * (KS * 1024);            // this chunk's k-step 0
+            float4 a0[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&pb[aoff[mt]]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (UP2 && ks == XK && park) __syncthreads();  // barrier X (see the producers' commit)
+                float4 a1[MT];
+                if (ks + 1 < KS) {                             // A fragments of the next k-step
+                    const int tap1 = (ks + 1) / (CK / 16), s1 = (ks + 1) % (CK / 16);
+                    const int off1 = ((tap1 / 3) * PW + (tap1 % 3)) * CKP + 8 * s1;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a1[mt] = *reinterpret_cast<const float4*>(&pb[aoff[mt] + off1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
+                                                                              __builtin_bit_cast(bf16x8, bq[ks % PFD][nt]), acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill the slot just read with k-step ks + PFD of the stream
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[ks % PFD][nt] = wload(wc + (ks + PFD) * 1024 + nt * wstride);
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
+                }
+            }
+        }
+
+        if (t_next < total) {                                  // the next tile's bias and first weight fragments
+            const int wn0 = wbase(t_next);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bias_v[nt] = a.bias[((t_next / tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
+#pragma unroll
+                for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wn0 + nt * wstride + p * 1024);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: LeakyReLU(0.2), NHWC store; two full 128-B lines per store instruction (per-slot address part in the scalar
+        // offset of a buffer store, per-lane part in one VGPR per N-block)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
+            const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh) * (unsigned)a.Cout + (unsigned)co) * 4u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
+                    const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
+                    const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
+                    const float v = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                    if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);             // one 32 x 32 block at a time: the weight ring stays in registers
+            }
+        }
+        WS_STAMP(0);
+        t = t_next;
+    }
+}
+
+template <int TW, int WM, int WN, int SRC>
+static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
+    constexpr int BYTES = bf16ws_lds_floats<TW, WM, SRC>() * 4;
+    static DeviceOnce once;
+    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, SRC>), BYTES, once);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, SRC>), dim3(grid), dim3(512), BYTES, s, a);
+    return hipGetLastError();
+}
+
+template <int TW, int WM, int WN>
+static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hipStream_t s) {
+    if (src_mode == SRC_PLAIN) return launch_one<TW, WM, WN, SRC_PLAIN>(a, grid, s);
+    if (src_mode == SRC_POOL && WN == 2) return launch_one<TW, 2, 2, SRC_POOL>(a, grid, s);
+    if (src_mode == SRC_UPCAT && a.Cskip % 32 == 0 && a.Cskip >= 32 && a.Cin - a.Cskip >= 32) return launch_one<TW, WM, WN, SRC_UPCAT>(a, grid, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
+    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 || a0.act16 != 0 || a0.pooled != nullptr ||
+        a0.last_w != nullptr)
+        return hipErrorInvalidValue;
+    ConvArgs a = a0;
+    a.tilesX = p.tiles_x;
+    a.tilesY = p.tiles_y;
+#ifdef PNP_WS_STAMPS
+    a.order = g_ws_slot < 64 ? g_ws_slot++ : 63;
+#endif
+    const long total = (long)p.tiles_x * p.tiles_y * a.N * (a.Cout / p.bn);
+    const unsigned grid = (unsigned)(total < 256 ? total : 256);     // persistent: one workgroup (8 waves) per CU
+    if (p.wn == 2) {
+        if (p.tw == 32) return launch_src<32, 2, 2>(a, src_mode, grid, s);
+        if (p.tw == 16) return launch_src<16, 2, 2>(a, src_mode, grid, s);
+    } else {
+        if (p.tw == 32) return launch_src<32, 4, 1>(a, src_mode, grid, s);
+        if (p.tw == 16) return launch_src<16, 4, 1>(a, src_mode, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pnp
+
+#ifdef PNP_WS_STAMPS
+extern "C" int pnp_debug_ws_stamps_reset(void) { g_ws_slot = 0; return 0; }
+extern "C" int pnp_debug_ws_stamps_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_stamps), sizeof(unsigned long long) * 64 * 2 * 128);
+}
+#endif

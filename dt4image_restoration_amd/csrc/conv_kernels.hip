@@ -45,7 +45,7 @@ const LayerSpec kLayers[N_LAYERS] = {
 // cannot hide its own LDS/global loads under it, so the k-loop rate is set by loads per MFMA: a 2x1 register
 // tile (MT x NT blocks of 32x32) runs at 74 cycles/MFMA, 2x2 at 69, 4x1 at 67.6, 4x2 at 66.2, 4x4 at 65.0 (64 is
 // the pipe).  So every config uses MT = 4 and the widest NT that Cout and the CU count allow.
-ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16) {
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src_mode, bool allow_ws) {
     ConvPlan p{};
     p.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     const long pixels = (long)N * H * W;
@@ -76,6 +76,19 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16) {
         if (sk > nchunks) sk = nchunks;
         while (nchunks % sk != 0) --sk;             // equal ranges
         p.splitk = sk;
+    }
+    // bf16 mode, chip-filling problems: the producer / consumer kernel (conv_bf16_kernels.hip) takes the layers with
+    // Cout >= 64 (sources PLAIN, UPCAT; POOL on the 256 x 128 tile), 512-pixel x 64-channel tiles for Cout = 64,
+    // 256 x 128 otherwise, always 32-channel chunks; it is persistent (one 8-wave workgroup per CU), so it wants >= 192 tiles
+    if (bf16 && allow_ws && p.splitk == 1 && p.mt == 4 && p.tw >= 16 && Cin % 32 == 0 && (Cout == 64 || Cout % 128 == 0) &&
+        (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT || (src_mode == SRC_POOL && Cout != 64))) {
+        ConvPlan q = p;
+        q.nt = 2; q.ck = 32;
+        if (Cout == 64) { q.wm = 4; q.wn = 1; } else { q.wm = 2; q.wn = 2; }
+        const ConvPlan keep = p;
+        p = q;
+        if (finish() >= 192) { p.ws = 1; return p; }
+        p = keep;
     }
     return p;
 }
@@ -597,6 +610,7 @@ static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, 
 
 hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
     if (a0.Cin % 32 != 0 || a0.Cout % 32 != 0 || (a0.Cout > 64 && a0.Cout % 128 != 0)) return hipErrorInvalidValue;
+    if (p.ws) return launch_conv3x3_bf16ws(a0, p, src_mode, s);
     const bool bf16 = a0.bf16 != 0;
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
@@ -646,6 +660,7 @@ Tuning tuning_from_env() {
     if (const char* v = getenv("PNP_WINO_F4_MT16")) t.f4_mt16 = atoi(v);
     if (const char* v = getenv("PNP_WINO_F4_ORDER")) t.f4_order = atoi(v) != 0;
     t.bf16_f32_acts = getenv("PNP_BF16_F32_ACTS") != nullptr;
+    t.bf16_no_ws = getenv("PNP_BF16_NO_WS") != nullptr;
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;
 }

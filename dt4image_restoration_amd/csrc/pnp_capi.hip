@@ -324,7 +324,7 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
                 t2.no_f4 = true;
                 e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, t2);
             }
-            e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16);
+            e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, !e->tune.bf16_no_ws);
             e->wino[li] = e->wplan[li].use && !bf16;
             if (e->wino[li]) continue;
             const size_t f = conv3x3_partial_floats(e->cplan[li], cfg->n, lh, lw, L.cout);
@@ -632,7 +632,7 @@ int pnp_conv_algorithms(pnp_handle e, int32_t* algo28) {
     PNP_API_BEGIN
     if (!e || !algo28) return fail(PNP_ERR_INVALID, "pnp_conv_algorithms: null argument");
     if (e->cfg.flags & PNP_FLAG_NO_DENOISER) return fail(PNP_ERR_STATE, "pnp_conv_algorithms: handle has no denoiser");
-    for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? e->wplan[i].algo : 0));
+    for (int i = 0; i < N_LAYERS; ++i) algo28[i] = i == 0 ? 2 : (i == N_LAYERS - 1 ? 3 : (e->wino[i] ? e->wplan[i].algo : (e->cplan[i].ws ? 5 : 0)));
     return PNP_OK;
     PNP_API_END("pnp_conv_algorithms")
 }

@@ -23,6 +23,7 @@ struct Tuning {
     bool no_f4_phased = false;    // PNP_NO_WINO_F4_PHASED: every F(4x4) layer on the all-waves-in-step schedule
     int f4_mt16 = 0;              // PNP_WINO_F4_MT16 (experiments): 0 = default rule, 1 = never, 2 = upsample+concat layers only, 3 = every
                                   // 64-channel-block layer on 16-tile M-blocks
+    bool bf16_no_ws = false;      // PNP_BF16_NO_WS (ablation): bf16 mode without the producer / consumer kernel (the round-2 kernel everywhere)
     bool bf16_f32_acts = false;   // PNP_BF16_F32_ACTS (ablation): bf16 mode keeps every activation in f32, as rounds 1-2 did
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
@@ -81,9 +82,11 @@ struct ConvPlan {
     int mt, nt, wm, wn; // M-/N-blocks (32x32) per wave; wave grid
     int ck;            // input channels per staged chunk (16 or 32)
     int splitk;        // K ranges (of whole chunks), one workgroup each; > 1 only on small problems
+    int ws;            // bf16 mode: the producer / consumer kernel (conv_bf16_kernels.hip) runs this layer; ck = 32
     int tiles_x, tiles_y;
 };
-ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false);
+ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false, int src_mode = SRC_PLAIN, bool allow_ws = true);
+hipError_t launch_conv3x3_bf16ws(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s);
 size_t conv3x3_partial_floats(const ConvPlan& p, int N, int H, int W, int Cout);
 bool conv3x3_pooled_output_ok(const ConvPlan& p);
 hipError_t launch_conv3x3(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s);

@@ -205,7 +205,8 @@ class PnPEngine:
         return out
 
     def conv_algorithms(self):
-        """Per conv layer: 0 direct MFMA, 1 Winograd MFMA, 2 first layer (VALU), 3 last layer."""
+        """Per conv layer: 0 direct MFMA, 1 Winograd F(2x2), 4 Winograd F(4x4), 2 first layer (VALU), 3 last layer,
+        5 bf16 producer/consumer kernel (bf16 mode, chip-filling problems)."""
         out = (C.c_int32 * _lib.N_LAYERS)()
         _lib.check(self.lib.pnp_conv_algorithms(self._h, out), "pnp_conv_algorithms")
         return list(out)

@@ -282,7 +282,8 @@ def test_512_accel8_bf16_convs_match_bf16_oracle(denoiser):
     sd = O.torch_weights(denoiser.weights)
     e = PnPEngine(n, h, w, bf16_convs=True)
     e.load_weights(denoiser.weights)
-    assert all(v == 0 for v in e.conv_algorithms()[1:27])                 # the bf16 direct kernel on every 3x3 layer
+    algos = e.conv_algorithms()[1:27]
+    assert all(v in (0, 5) for v in algos) and algos[4] == 5                # bf16 direct kernels; level 1 fills the chip: producer/consumer form
     gt = torch.from_numpy(data["gt"]).cuda()
     x, z, u = e.reset(torch.view_as_complex(torch.from_numpy(data["x0"])).cuda(),
                       torch.view_as_complex(torch.from_numpy(data["y0"])).cuda(), torch.from_numpy(data["mask"]).cuda())
@@ -298,6 +299,46 @@ def test_512_accel8_bf16_convs_match_bf16_oracle(denoiser):
     # FLOAT TOLERANCE: bf16 operand rounding flips (2^-9 relative) reach the image at ~1e-3 (test_gpu_kernels.py)
     assert float((x.cpu() - sb["x"]).abs().max()) < 3e-3
     assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+
+
+def test_bf16_batch64_plan_matches_bf16_oracle_and_skips_stopped_slices(denoiser):
+    """The plan `bench.py --convs bf16` times (64 x 256x256): every conv with Cout >= 64 on the producer/consumer kernel
+    (conv_bf16_kernels.hip: all four tile variants; PLAIN, POOL and upsample-concat sources), level 0 exchanging bf16
+    activations.  One denoiser pass on all 64 slices against the oracle's bf16-operand mode (noise.py:155-164 with the
+    same rounding points); then one ADMM step with a third of the slices stopped (env.py:74-100 `T`): those keep x, z, u bit
+    for bit - the persistent kernels skip their tiles - and the others equal a step of the same state with nobody stopped."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    from oracle import pnp_oracle as O
+    n, h, w = 64, 256, 256
+    e = PnPEngine(n, h, w, bf16_convs=True)
+    e.load_weights(denoiser.weights)
+    algos = e.conv_algorithms()
+    for li in range(1, 27):
+        spec_cout = [32, 64, 128, 256, 512, 256, 128, 64, 32][li // 3]
+        assert algos[li] == (5 if spec_cout >= 64 else 0), (li, algos[li])
+    sd = O.torch_weights(denoiser.weights)
+    x = ((torch.from_numpy(synthetic.hash_uniform(9, 64256, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5)
+    sigma = torch.linspace(3, 60, n) / 255.0
+    got = e.denoise(x.cuda(), sigma.cuda()).cpu()
+    ref = O.denoise(sd, x, sigma, bf16_operands=True)
+    # FLOAT TOLERANCE: bf16 operand rounding flips (2^-9 relative) reach the image at ~1e-3 (test_gpu_kernels.py)
+    assert float((got - ref).abs().max()) < 3e-3
+    assert float((got - ref).abs().mean()) < 3e-4                          # measured 1.0e-4 (max 7e-4), the round-2 kernel's figure too
+    data = synthetic.make_problem(n, h, w, accel=4.0, seed=99)
+    x0, z0, u0 = e.reset(torch.view_as_complex(torch.from_numpy(data["x0"])).cuda(),
+                         torch.view_as_complex(torch.from_numpy(data["y0"])).cuda(), torch.from_numpy(data["mask"]).cuda())
+    mu, sg = torch.full((n,), 0.4).cuda(), torch.full((n,), 0.08).cuda()
+    e.step(x0, z0, u0, mu, sg)                                             # a state with u != 0
+    xa, za, ua = x0.clone(), z0.clone(), u0.clone()
+    xb, zb, ub = x0.clone(), z0.clone(), u0.clone()
+    tact = torch.zeros(n)
+    tact[::3] = 1.0
+    e.step(xa, za, ua, mu, sg, t_action=tact.cuda())
+    e.step(xb, zb, ub, mu, sg)
+    stop = tact > 0.5
+    for a_, b_, o_ in ((xa, xb, x0), (za, zb, z0), (ua, ub, u0)):
+        assert torch.equal(a_[stop], o_[stop])
+        assert torch.equal(a_[~stop], b_[~stop])
 
 
 def test_256_batch4_30_iterations_all_winograd_plan(golden_dir, monkeypatch):
