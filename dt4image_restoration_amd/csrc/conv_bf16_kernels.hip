@@ -44,7 +44,10 @@ constexpr int bf16ws_lds_floats() {
     return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0);
 }
 
-template <int TW, int WM, int WN, int SRC>
+// A16S: src0 (the PLAIN / POOL source, the UPCAT skip tensor) holds bf16 - written so by the launch that produced it, rounded
+// once with the rounding this staging would apply (same patch bits, half the HBM bytes; ConvArgs.act16 bit 0); dst holds
+// bf16 when a.act16 has bit 1.  The low-res source of an upsample stays f32: its consumer rounds AFTER interpolating.
+template <int TW, int WM, int WN, int SRC, bool A16S>
 __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     constexpr int MT = 4, NT = 2, CK = 32;
     constexpr int KS = 9 * (CK / 16);   // k-steps (16 channels) per chunk
@@ -67,8 +70,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3, CKL = CK + 4;
     constexpr int NITL = (LH * LW * PPP + 255) / 256;
     constexpr int XK = 2;               // the consumers' k-step in front of which barrier X sits
-    static_assert(NITL <= NIT, "a raw set holds either kind of item");
-    static_assert(PPP == 8, "256 producer lanes = 32 pixels x 8 pieces per pass");
+    static_assert(PPP == 8, "256 producer lanes = 32 pixels x 8 f32 pieces per pass");
+    // src0 pieces: 16 B = 4 f32 or 8 bf16 channels; the 256 producer lanes cover PXP pixels x PPS pieces per pass
+    constexpr int ESZ = A16S ? 2 : 4;
+    constexpr int PPS = CK * ESZ / 16, PXP = 256 / PPS;
+    constexpr int NITS = (PH * PW + PXP - 1) / PXP;
+    constexpr int NR = (UP2 && NITL > NITS) ? NITL : NITS;   // a raw set holds either kind of item
     extern __shared__ __attribute__((aligned(16))) float patch[];   // bf16ws_lds_floats(): 54-130 KB, dynamic
     float* const lowres = patch + 2 * PATCH;                        // UPCAT: [LH * LW][CKL]
     float* const tabs = lowres + LH * LW * CKL;                     // UPCAT: [2][PH + PW] x {offset of source line 0, 1; weight 0, 1}
@@ -103,41 +110,44 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         // image" (once per tile; the buffer load's range check then returns the conv's zero padding) and LDS addresses that
         // differ by constants are all the state; per chunk a piece costs one buffer load, two converts and one LDS store.
         const int ptid = tid - 256;
-        const int part = ptid % PPP, p0 = ptid / PPP;
+        const int part = ptid % PPP, p0 = ptid / PPP;          // f32 geometry: low-res pieces, interpolated pieces
+        const int partS = ptid % PPS, p0S = ptid / PPS;        // src0 geometry
         constexpr int SRCMUL = SRC == SRC_POOL ? 2 : 1;        // POOL: the source is 2H x 2W (noise.py:22-25 MaxPool2d(2))
         const int Hs = SRCMUL * a.H, Ws = SRCMUL * a.W;
-        int pyx[NIT];                                          // (py << 16) | px of piece k's patch pixel; -1: no such piece
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int pp = p0 + 32 * k;
-            pyx[k] = pp < PH * PW ? (((pp / PW) << 16) | (pp % PW)) : -1;
-        }
-        int lyx[UP2 ? NITL : 1];                               // same for the low-res region's pieces
+        const int C0 = UP2 ? a.Cskip : a.Cin;                  // channels of the tensor behind src0
+        int pyx[UP2 ? NIT : 1];                                // UPCAT: (py << 16) | px of the patch pixel of interpolated piece k
+        int lyx[UP2 ? NITL : 1];                               // same for the low-res region's pieces; -1: no such piece
         if constexpr (UP2) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int pp = p0 + 32 * k;
+                pyx[k] = pp < PH * PW ? (((pp / PW) << 16) | (pp % PW)) : -1;
+            }
 #pragma unroll
             for (int k = 0; k < NITL; ++k) {
                 const int lp = p0 + 32 * k;
                 lyx[k] = lp < LH * LW ? (((lp / LW) << 16) | (lp % LW)) : -1;
             }
         }
-        unsigned goff[NIT];
+        unsigned goff[NITS];
         unsigned goffL[UP2 ? NITL : 1];
         __amdgpu_buffer_rsrc_t rsrcL;
         int tile_par = 1;                                      // parity of the tile decoded last (UPCAT tables)
-        typedef float4 RawSet[NIT][NRAW];
-        RawSet raw0, raw1;                                     // items alternate between the two sets: two items' loads in flight (PLAIN)
+        typedef float4 RawSet[NR][NRAW];
+        RawSet raw0, raw1;                                     // items alternate between the two sets: two items' loads in flight
         __amdgpu_buffer_rsrc_t rsrc;
         auto decode = [&](int tt) {
             const int m = tt % tilesM;
             const int tx0 = (m % a.tilesX) * TW, ty0 = ((m / a.tilesX) % a.tilesY) * TH, n = m / (a.tilesX * a.tilesY);
-            const int C0 = UP2 ? a.Cskip : a.Cin;                  // channels of the tensor behind src0
             const size_t slice = (size_t)Hs * Ws * C0;
-            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * slice), 0, (int)(slice * sizeof(float)), 0x00020000);
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.src0) + (size_t)n * slice * ESZ), 0,
+                                                     (int)(slice * ESZ), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int gy = ty0 + (pyx[k] >> 16) - 1, gx = tx0 + (pyx[k] & 0xffff) - 1;
-                const bool in = pyx[k] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                goff[k] = in ? (unsigned)(((SRCMUL * gy) * Ws + SRCMUL * gx) * C0 + part * 4) * 4u : 0x80000000u;
+            for (int k = 0; k < NITS; ++k) {
+                const int pp = p0S + PXP * k;
+                const int gy = ty0 + pp / PW - 1, gx = tx0 + pp % PW - 1;
+                const bool in = pp < PH * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                goff[k] = in ? (unsigned)(((SRCMUL * gy) * Ws + SRCMUL * gx) * C0 * ESZ + partS * 16) : 0x80000000u;
             }
             if constexpr (UP2) {
                 const int Hl = a.H >> 1, Wl = a.W >> 1, Cup = a.Cin - a.Cskip;
@@ -179,21 +189,30 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                     return;
                 }
             }
-            const int so = c * CK * 4;
+            const int so = c * CK * ESZ;
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
+            for (int k = 0; k < NITS; ++k) {
                 raw[k][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so, 0));
                 if constexpr (SRC == SRC_POOL) {
-                    raw[k][NRAW > 1 ? 1 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + a.Cin * 4, 0));
-                    raw[k][NRAW > 1 ? 2 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + Ws * a.Cin * 4, 0));
-                    raw[k][NRAW > 1 ? 3 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + (Ws + 1) * a.Cin * 4, 0));
+                    raw[k][NRAW > 1 ? 1 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + C0 * ESZ, 0));
+                    raw[k][NRAW > 1 ? 2 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + Ws * C0 * ESZ, 0));
+                    raw[k][NRAW > 1 ? 3 : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k], so + (Ws + 1) * C0 * ESZ, 0));
                 }
             }
         };
-        auto store_bf16 = [&](float* buf, int k, float4 v) {
-            const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);   // round to nearest even
+        auto store_bf16 = [&](float* buf, int k, float4 v) {   // piece k of the f32 geometry: 4 channels, rounded to nearest even
+            const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
             const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
             *reinterpret_cast<uint2*>(&buf[(p0 + 32 * k) * CKP + part * 2]) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+        };
+        auto max16 = [](unsigned x, unsigned y) {              // max of two packed bf16 pairs (exact: bf16 -> f32 is a shift)
+            const float lo = fmaxf(__uint_as_float(x << 16), __uint_as_float(y << 16));
+            const float hi = fmaxf(__uint_as_float(x & 0xffff0000u), __uint_as_float(y & 0xffff0000u));
+            return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+        };
+        auto f4max16 = [&](float4 x, float4 y) {
+            return make_float4(__uint_as_float(max16(__float_as_uint(x.x), __float_as_uint(y.x))), __uint_as_float(max16(__float_as_uint(x.y), __float_as_uint(y.y))),
+                               __uint_as_float(max16(__float_as_uint(x.z), __float_as_uint(y.z))), __uint_as_float(max16(__float_as_uint(x.w), __float_as_uint(y.w))));
         };
         auto commit = [&](float* buf, const RawSet& raw, int meta) {   // meta (UPCAT): bit 0 = upsampled chunk, bit 1 = its tile's parity
             if constexpr (UP2) {
@@ -220,12 +239,18 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                if (p0 + 32 * k < PH * PW) {                     // (out-of-image pieces loaded zeros: the conv's zero padding)
+            for (int k = 0; k < NITS; ++k) {
+                if (p0S + PXP * k < PH * PW) {                   // (out-of-image pieces loaded zeros: the conv's zero padding)
                     float4 v = raw[k][0];
-                    if constexpr (SRC == SRC_POOL)
-                        v = f4max(f4max(raw[k][0], raw[k][NRAW > 1 ? 1 : 0]), f4max(raw[k][NRAW > 1 ? 2 : 0], raw[k][NRAW > 1 ? 3 : 0]));
-                    store_bf16(buf, k, v);
+                    if constexpr (A16S) {
+                        if constexpr (SRC == SRC_POOL)
+                            v = f4max16(f4max16(raw[k][0], raw[k][NRAW > 1 ? 1 : 0]), f4max16(raw[k][NRAW > 1 ? 2 : 0], raw[k][NRAW > 1 ? 3 : 0]));
+                        *reinterpret_cast<float4*>(&buf[(p0S + PXP * k) * CKP + partS * 4]) = v;      // bf16 already
+                    } else {
+                        if constexpr (SRC == SRC_POOL)
+                            v = f4max(f4max(raw[k][0], raw[k][NRAW > 1 ? 1 : 0]), f4max(raw[k][NRAW > 1 ? 2 : 0], raw[k][NRAW > 1 ? 3 : 0]));
+                        store_bf16(buf, k, v);
+                    }
                 }
             }
         };
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         };
         issue_next(raw0, meta0, true);
         WS_STAMP(1);
-        if constexpr (NRAW == 1 && !(UP2 && NIT > 12)) {
+        if constexpr (NRAW == 1 && !(UP2 && NR > 12)) {
             issue_next(raw1, meta1, false);
             for (;;) {
                 if (!step(raw0, meta0, patch)) break;
@@ -284,6 +309,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
     const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc16 = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * 2), 0x00020000);
     // What a tile needs from memory besides its patches is requested ahead, so that a tile boundary costs the consumers no
     // round trip: the next live tile (a tact[] read) at the start of this one, its bias values and the first PFD k-steps
     // of its weights right after this tile's last k-loop - they land under the epilogue's stores.  (The ring's refills of a
@@ -372,23 +398,50 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // epilogue: LeakyReLU(0.2), NHWC store; two full 128-B lines per store instruction (per-slot address part in the scalar
-        // offset of a buffer store, per-lane part in one VGPR per N-block)
+        // epilogue: LeakyReLU(0.2), NHWC store; per-slot address part in the scalar offset of a buffer store, per-lane part in
+        // one VGPR per N-block
+        if (a.act16 & 2) {
+            // bf16 dst: lanes (2j, 2j+1) hold channels (2j, 2j+1) of the same pixels; they swap one value per pixel PAIR
+            // (DPP quad_perm [1,0,3,2]) so that the even lane stores pixel r's channel pair and the odd lane pixel r+1's:
+            // 4 B per lane, 64 B contiguous per pixel, half the store instructions of the f32 form
+            const bool odd = (li & 1) != 0;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
-            const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh) * (unsigned)a.Cout + (unsigned)co) * 4u;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + (li & ~1);
+                const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh + (odd ? 1 : 0)) * (unsigned)a.Cout + (unsigned)co) * 2u;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
-                    const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
-                    const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
-                    const float v = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
-                    if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                    for (int r = 0; r < 16; r += 2) {
+                        const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // pixel of register r (r + 1: the next pixel in the row)
+                        const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh + (odd ? 1 : 0);
+                        const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 2);
+                        const float x = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                        const float y = fmaxf(acc[mt][nt][r + 1], kLeaky * acc[mt][nt][r + 1]);
+                        const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? x : y), 0xB1, 0xf, 0xf, false));
+                        const bf16x2 pk = __builtin_convertvector((f32x2){odd ? got : x, odd ? y : got}, bf16x2);   // round to nearest even
+                        if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), orsrc16, obase, soff, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);             // one 32 x 32 block at a time: the weight ring stays in registers
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
+                const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh) * (unsigned)a.Cout + (unsigned)co) * 4u;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
+                        const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
+                        const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
+                        const float v = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                        if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // one 32 x 32 block at a time: the weight ring stays in registers
+                }
             }
         }
         WS_STAMP(0);
@@ -396,14 +449,19 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
 }
 
-template <int TW, int WM, int WN, int SRC>
-static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
+template <int TW, int WM, int WN, int SRC, bool A16S>
+static hipError_t launch_k(const ConvArgs& a, unsigned grid, hipStream_t s) {
     constexpr int BYTES = bf16ws_lds_floats<TW, WM, SRC>() * 4;
     static DeviceOnce once;
-    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, SRC>), BYTES, once);
+    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, SRC, A16S>), BYTES, once);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, SRC>), dim3(grid), dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, SRC, A16S>), dim3(grid), dim3(512), BYTES, s, a);
     return hipGetLastError();
+}
+
+template <int TW, int WM, int WN, int SRC>
+static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
+    return (a.act16 & 1) ? launch_k<TW, WM, WN, SRC, true>(a, grid, s) : launch_k<TW, WM, WN, SRC, false>(a, grid, s);
 }
 
 template <int TW, int WM, int WN>
@@ -415,7 +473,7 @@ static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hip
 }
 
 hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
-    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 || a0.act16 != 0 || a0.pooled != nullptr ||
+    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 || a0.pooled != nullptr ||
         a0.last_w != nullptr)
         return hipErrorInvalidValue;
     ConvArgs a = a0;

@@ -92,6 +92,7 @@ struct pnp_engine {
     bool fuse_first = false;          // first layer (2 -> 32) is computed in the staging of inc.conv-1 (F(4x4) 32-channel variant)
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
     bool act16 = false;               // bf16 mode: the 32-channel level-0 activations (lv[0].p/q/s) are stored as bf16 (ConvArgs.act16)
+    uint8_t abits[N_LAYERS] = {};     // bf16 mode, per conv layer: ConvArgs.act16 (bit 0: src0 holds bf16, bit 1: dst holds bf16)
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
@@ -174,7 +175,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         a.pooled = pooled;
         a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
         a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
-        if (e->act16 && lvl == 0) a.act16 = li == 26 ? 1 : 3;     // level 0 reads and writes bf16; the unfused 1x1 conv reads f32
+        a.act16 = e->abits[li];
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
             const int hs = a.H / 2, ws = a.W / 2;
@@ -223,7 +224,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         ConvArgs a{};
         a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
         a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
-        a.act16 = e->act16 ? 1 : 0;
+        a.act16 = e->abits[26] & 1;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
         {
@@ -350,6 +351,31 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
         // (always so today); a KEEP_STAGES handle keeps f32 stages for pnp_unet_read_stage.
         e->act16 = bf16 && !(cfg->flags & PNP_FLAG_KEEP_STAGES) && !e->tune.bf16_f32_acts && e->pool_ok[0];
         for (int li : {1, 2, 24, 25, 26}) e->act16 = e->act16 && conv3x3_pooled_output_ok(e->cplan[li]);
+        if (e->act16) {
+            // ... and so do the layers of the producer / consumer kernel among themselves: a tensor is bf16 when the launch that
+            // writes it and every launch that reads it as src0 (next layer, PLAIN or POOL; the decoder layer taking it as its
+            // skip tensor) can; the low-res input of an upsample (outputs of layers 14, 17, 20, 23) stays f32 - its consumer
+            // rounds after interpolating - and so do the pooled copy of level 0 and the input of the unfused 1x1 conv
+            auto can = [&](int li) { return li >= 1 && li <= 26 && ((li < 3 || li > 23) || e->cplan[li].ws != 0); };
+            bool out16[N_LAYERS] = {};
+            out16[0] = true;                                       // conv_first -> inc.conv-1
+            for (int li = 1; li <= 25; ++li) {
+                if (li == 14 || li == 17 || li == 20 || li == 23) continue;
+                const int skip_reader = li == 2 ? 24 : (li == 5 ? 21 : (li == 8 ? 18 : (li == 11 ? 15 : 0)));
+                // (a stage's last layer: the next stage reads the f32 pooled copy instead when there is one)
+                const bool next_reads = !(skip_reader != 0 && e->pool_ok[kLayers[li].level]);
+                out16[li] = can(li) && (!next_reads || can(li + 1)) && (skip_reader == 0 || can(skip_reader));
+            }
+            for (int li = 1; li <= 26; ++li) {
+                bool in16;
+                if (li == 3) in16 = false;                          // down1.conv-0 reads the f32 pooled copy of level 0
+                else if (li == 15 || li == 18 || li == 21 || li == 24) in16 = out16[li == 15 ? 11 : (li == 18 ? 8 : (li == 21 ? 5 : 2))];
+                else in16 = out16[li - 1];
+                // the level-0 kernel writes bf16 only from its bf16-source variant
+                if ((li < 3 || li > 23) && !in16) out16[li] = false;
+                e->abits[li] = (uint8_t)((in16 ? 1 : 0) | (out16[li] ? 2 : 0));
+            }
+        }
     }
     const size_t cbytes = N * H * W * sizeof(float2);
     if (hipMalloc((void**)&e->d_work, cbytes) != hipSuccess || hipMalloc((void**)&e->d_y0s, cbytes) != hipSuccess ||
@@ -614,7 +640,8 @@ int pnp_unet_read_stage(pnp_handle e, int which, float* dst, int* c, int* hh, in
     PNP_API_BEGIN
     if (!e || which < 0 || which > 8) return fail(PNP_ERR_INVALID, "pnp_unet_read_stage: which must be 0..8");
     if (which == 8 && e->fuse_last) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 8 is fused away; create the handle with PNP_FLAG_KEEP_STAGES");
-    if (which == 0 && e->act16) return fail(PNP_ERR_STATE, "pnp_unet_read_stage: stage 0 is held as bf16 on this handle; create it with PNP_FLAG_KEEP_STAGES");
+    if (which <= 3 && (e->abits[3 * which + 2] & 2))
+        return fail(PNP_ERR_STATE, "pnp_unet_read_stage: this stage is held as bf16 on this handle; create it with PNP_FLAG_KEEP_STAGES");
     PNP_ON_DEVICE(e);
     // stage outputs: inc, down1..4 live in lv[k].s; up1..4 in lv[3..0].p
     const int lvl = which <= 4 ? which : 8 - which;

@@ -267,12 +267,13 @@ def test_bf16_convs_trajectory_psnr_offsets(sd_np):
         assert float((p - O.psnr(sf["x"], sf["gt"]).reshape(-1)).abs().max()) < 0.01
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 128, 128), (3, 48, 80), (1, 256, 256)])
+@pytest.mark.parametrize("n,h,w", [(2, 128, 128), (3, 48, 80), (1, 256, 256), (16, 256, 256), (64, 256, 256)])
 def test_bf16_activation_storage_is_bit_neutral(sd_np, n, h, w, monkeypatch):
-    """bf16 mode keeps the 32-channel level-0 activations in HBM as bf16 (ConvArgs.act16): the producer rounds once with the
-    rounding the consumer's staging would apply, so the denoiser output must equal - bit for bit - the output of a handle
-    that keeps those tensors in f32 (PNP_BF16_F32_ACTS, the layout of rounds 1-2).  Stage 0 of such a handle is not readable
-    as f32 and says so."""
+    """bf16 mode keeps activations in HBM as bf16 wherever producer and consumers can (ConvArgs.act16: level 0 always; at
+    16 x 256x256 also levels 1-2, whose layers run the producer/consumer kernel, with f32 hand-overs to levels 3-4; at
+    64 x 256x256 every tensor that does not feed an upsample): the producer rounds once with the rounding the consumer's
+    staging would apply, so the denoiser output must equal - bit for bit - the output of a handle that keeps those
+    tensors in f32 (PNP_BF16_F32_ACTS, the layout of rounds 1-2).  Stage 0 of such a handle is not readable as f32 and says so."""
     from dt4image_restoration_amd.engine import PnPEngine
     x = ((torch.from_numpy(synthetic.hash_uniform(5, h * 1000 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
     sigma = (torch.linspace(5, 50, n) / 255.0).cuda()
