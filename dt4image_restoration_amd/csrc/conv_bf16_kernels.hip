@@ -38,21 +38,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS floats of a workgroup: two patches of (TH+2) x (TW+2) pixels x 80 B; UPCAT adds the f32 low-res source region of one
 // upsampled chunk ((TH/2+3) x (TW/2+3) pixels x 36 floats) and two copies (tile parity) of the interpolation table.
-template <int TW, int WM, int SRC>
+// The 32-channel tile (NT = 1) adds its epilogue's transpose space, 36 floats per tile pixel.
+template <int TW, int WM, int MT, int NT, int SRC>
 constexpr int bf16ws_lds_floats() {
-    constexpr int TH = WM * 128 / TW, PH = TH + 2, PW = TW + 2;
-    return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0);
+    constexpr int TH = WM * MT * 32 / TW, PH = TH + 2, PW = TW + 2;
+    return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0) +
+           (NT == 1 ? WM * MT * 32 * 36 : 0) + 256;         // + the stopped-tile flags
 }
 
 // A16S: src0 (the PLAIN / POOL source, the UPCAT skip tensor) holds bf16 - written so by the launch that produced it, rounded
 // once with the rounding this staging would apply (same patch bits, half the HBM bytes; ConvArgs.act16 bit 0); dst holds
 // bf16 when a.act16 has bit 1.  The low-res source of an upsample stays f32: its consumer rounds AFTER interpolating.
-template <int TW, int WM, int WN, int SRC, bool A16S>
+//
+// Register tiles (MT x NT blocks of 32 x 32 per consumer wave): 4 x 2 for Cout >= 64 (256 pixels x 128 channels per workgroup,
+// or 512 x 64 for Cout = 64), 2 x 1 for the 32-channel level-0 layers (256 x 32; HBM-bound even on bf16 tensors, so its
+// epilogue goes through LDS for 16-B stores, the pooled copy of the next stage and the fused last layer, as in
+// conv_kernels.hip).
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S>
 __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
-    constexpr int MT = 4, NT = 2, CK = 32;
+    constexpr int CK = 32;
     constexpr int KS = 9 * (CK / 16);   // k-steps (16 channels) per chunk
-    constexpr int PFD = 6;              // weight fragments in flight, k-steps ahead (divides KS: k-step j sits in slot j % PFD)
+    // weight fragments in flight, k-steps ahead (divides KS: k-step j sits in slot j % PFD): 6 x 256 MFMA cycles for the 4 x 2
+    // tile; the 2 x 1 tile's k-step is 64 cycles, it keeps a whole chunk ahead
+    constexpr int PFD = MT * NT >= 8 ? 6 : 18;
     static_assert(KS % PFD == 0 && WM * WN == 4, "ring / wave grid");
+    static_assert(NT == 2 || (NT == 1 && WN == 1 && TW == 32 && MT == 2), "32-channel tile: a wave owns two whole tile rows");
     constexpr int CKP = (CK + 8) / 2;   // patch pixel stride in floats (CK + 8 halves: b128 lane groups on distinct banks)
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int TH = BM / TW, PH = TH + 2, PW = TW + 2;
@@ -78,7 +88,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     constexpr int NR = (UP2 && NITL > NITS) ? NITL : NITS;   // a raw set holds either kind of item
     extern __shared__ __attribute__((aligned(16))) float patch[];   // bf16ws_lds_floats(): 54-130 KB, dynamic
     float* const lowres = patch + 2 * PATCH;                        // UPCAT: [LH * LW][CKL]
-    float* const tabs = lowres + LH * LW * CKL;                     // UPCAT: [2][PH + PW] x {offset of source line 0, 1; weight 0, 1}
+    float* const tabs = lowres + (UP2 ? LH * LW * CKL : 0);         // UPCAT: [2][PH + PW] x {offset of source line 0, 1; weight 0, 1}
+    float* const epi = tabs + (UP2 ? 2 * 4 * (PH + PW) : 0);        // NT = 1: [BM][36] output tile, a wave's rows private to it
     const int nskip = UP2 ? a.Cskip / CK : 0;
 
     const int tid = threadIdx.x;
@@ -88,9 +99,49 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     const int total = tilesM * (a.Cout / BN);
     const int nchunks = a.Cin / CK;
     // tile t: output-channel block cb = t / tilesM is the slow index, so the chip streams one block's weights at a time
-    auto slice_of = [&](int t) { return (t % tilesM) / (a.tilesX * a.tilesY); };
+    // (tile indices stay far below 2^23: quotient from the float reciprocal, one correction step either way - a dozen instructions
+    // instead of the ~35 of a 32-bit division, and a tile decode has five of them)
+    auto fdiv = [](int x, int d, float rd) {
+        int q = (int)((float)x * rd);
+        const int r = x - q * d;
+        q += r >= d ? 1 : 0;
+        q -= r < 0 ? 1 : 0;
+        return q;
+    };
+    const int tilesXY = a.tilesX * a.tilesY;
+    const float r_tilesM = 1.f / (float)tilesM, r_tilesXY = 1.f / (float)tilesXY, r_tilesX = 1.f / (float)a.tilesX;
+    struct TileAt { int cb, n, ty0, tx0; };
+    auto tile_at = [&](int tt) {
+        TileAt o;
+        o.cb = fdiv(tt, tilesM, r_tilesM);
+        const int m = tt - o.cb * tilesM;
+        o.n = fdiv(m, tilesXY, r_tilesXY);
+        const int mm = m - o.n * tilesXY;
+        const int ty = fdiv(mm, a.tilesX, r_tilesX);
+        o.ty0 = ty * TH;
+        o.tx0 = (mm - ty * a.tilesX) * TW;
+        return o;
+    };
+    auto slice_of = [&](int t) { return tile_at(t).n; };
+    // Stopped slices (tact[n] > 0.5) are skipped tile by tile.  The flags of this workgroup's tiles - blockIdx.x, + gridDim.x,
+    // ... - are fetched once into LDS: a read of tact[] per tile is a memory round trip in both roles' critical paths, and
+    // a 32-channel tile is only ~2 us of work.
+    constexpr int MAXLIVE = 256;
+    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? BM * 36 : 0));
+    const int mine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+    const bool cached = a.tact != nullptr && mine <= MAXLIVE;
+    if (cached) {
+        if (tid < mine) stopped[tid] = a.tact[slice_of((int)blockIdx.x + tid * (int)gridDim.x)] > 0.5f ? 1 : 0;
+        __syncthreads();
+    }
     auto next_live = [&](int t) {       // first tile >= t (stride gridDim.x) whose slice is still running
-        while (t < total && a.tact != nullptr && a.tact[slice_of(t)] > 0.5f) t += (int)gridDim.x;
+        if (a.tact == nullptr) return t;
+        if (cached) {
+            int i = (t - (int)blockIdx.x) / (int)gridDim.x;
+            while (i < mine && stopped[i] != 0) ++i;
+            return (int)blockIdx.x + i * (int)gridDim.x;
+        }
+        while (t < total && a.tact[slice_of(t)] > 0.5f) t += (int)gridDim.x;
         return t;
     };
 #ifdef PNP_WS_STAMPS
@@ -137,8 +188,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         RawSet raw0, raw1;                                     // items alternate between the two sets: two items' loads in flight
         __amdgpu_buffer_rsrc_t rsrc;
         auto decode = [&](int tt) {
-            const int m = tt % tilesM;
-            const int tx0 = (m % a.tilesX) * TW, ty0 = ((m / a.tilesX) % a.tilesY) * TH, n = m / (a.tilesX * a.tilesY);
+            const TileAt ta = tile_at(tt);
+            const int tx0 = ta.tx0, ty0 = ta.ty0, n = ta.n;
             const size_t slice = (size_t)Hs * Ws * C0;
             rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.src0) + (size_t)n * slice * ESZ), 0,
                                                      (int)(slice * ESZ), 0x00020000);
@@ -322,22 +373,22 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     const int wlane = lane * 16;
     const int wstride = nchunks * KS * 1024;                                       // bytes between N-blocks
     auto wbase = [&](int tt) {          // byte offset of the weight stream of tile tt, this wave's N-block 0
-        return ((tt / tilesM) * (WN * NT) + wn * NT) * wstride;
+        return (fdiv(tt, tilesM, r_tilesM) * (WN * NT) + wn * NT) * wstride;
     };
     auto wload = [&](int soff) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, soff, 0)); };
     float4 bq[PFD][NT];
     float bias_v[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        bias_v[nt] = a.bias[((t / tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
+        bias_v[nt] = a.bias[(fdiv(t, tilesM, r_tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
 #pragma unroll
         for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wbase(t) + nt * wstride + p * 1024);
     }
     int g = 0;
     WS_STAMP(0);
     while (t < total) {
-        const int cbt = t / tilesM, m = t % tilesM;
-        const int tx0 = (m % a.tilesX) * TW, ty0 = ((m / a.tilesX) % a.tilesY) * TH, n = m / (a.tilesX * a.tilesY);
+        const TileAt ta = tile_at(t);
+        const int cbt = ta.cb, tx0 = ta.tx0, ty0 = ta.ty0, n = ta.n;
         const int t_next = next_live(t + (int)gridDim.x);      // (its loads fly under this tile's k-loops)
         const int wtile = wbase(t);
         f32x16 acc[MT][NT];
@@ -356,6 +407,9 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             const bool park = UP2 && c + 1 < nchunks && c + 1 >= nskip;   // the producers park a low-res region during this k-loop
             const float* pb = patch + (g & 1) * PATCH;
             const int wc = wtile + c * (KS * 1024);            // this chunk's k-step 0
+            // the 2 x 1 tile keeps a whole chunk of fragments ahead, refilled in place: past the tile's last chunk the stream goes on
+            // with the next tile's first (few registers here, and its short epilogue would not cover a re-prime)
+            const int wfollow = (NT == 1 && c + 1 == nchunks) ? wbase(t_next < total ? t_next : t) : wc + KS * 1024;
             float4 a0[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&pb[aoff[mt]]);
@@ -380,7 +434,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 // refill the slot just read with k-step ks + PFD of the stream
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bq[ks % PFD][nt] = wload(wc + (ks + PFD) * 1024 + nt * wstride);
+                    bq[ks % PFD][nt] = wload((NT == 1 ? wfollow + (ks + PFD - KS) * 1024 : wc + (ks + PFD) * 1024) + nt * wstride);
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
@@ -392,12 +446,89 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             const int wn0 = wbase(t_next);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                bias_v[nt] = a.bias[((t_next / tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
+                bias_v[nt] = a.bias[(fdiv(t_next, tilesM, r_tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
+                if constexpr (NT != 1) {
 #pragma unroll
-                for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wn0 + nt * wstride + p * 1024);
+                    for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wn0 + nt * wstride + p * 1024);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT == 1) {
+            // 32-channel tile: LeakyReLU(0.2), then through the wave's own rows of the LDS output tile - no barrier: a wave reads
+            // back only what it wrote - so that global stores are 16 B per lane over whole pixels, and the 2x2 max-pooled copy for
+            // the next stage (noise.py:22-25) or the fused last layer (1x1 conv 32 -> 1 + image residual + clamp, noise.py:67,
+            // 130-133,164; this conv's own output is then never written) come from the same tile
+            constexpr int OSTR = 36, WPX = MT * 32;            // a wave's pixels: WPX / TW = 2 whole tile rows
+            float* const ew = epi + wid * WPX * OSTR;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ew[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * OSTR + li] = fmaxf(acc[mt][0][r], kLeaky * acc[mt][0][r]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int wy0 = ty0 + wid * (WPX / TW);            // the wave's first image row
+            if (a.last_w != nullptr) {
+                const int gy = wy0 + lane / TW, gx = tx0 + lane % TW;          // one pixel per lane
+                if (gy < a.H && gx < a.W) {
+                    float dsum = a.last_b[0];
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 v = *reinterpret_cast<const float4*>(&ew[lane * OSTR + 4 * c4]);
+                        const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * c4);
+                        dsum += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                    }
+                    const size_t q = ((size_t)n * a.H + gy) * a.W + gx;
+                    const float img = a.last_ximg != nullptr ? a.last_ximg[q] : (a.last_z[q].x - a.last_u[q].x);
+                    a.last_out[q] = fminf(fmaxf(img + dsum, 0.f), 1.f);
+                }
+            } else {
+                if (a.act16 & 2) {                              // bf16 dst: 8 channels (16 B) per lane, 64 B per pixel
+                    uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
+#pragma unroll
+                    for (int j = 0; j < WPX * 4 / 64; ++j) {
+                        const int f = lane + 64 * j, px = f / 4, c8 = f % 4;
+                        const int gy = wy0 + px / TW, gx = tx0 + px % TW;
+                        if (gy < a.H && gx < a.W) {
+                            const float4 v0 = *reinterpret_cast<const float4*>(&ew[px * OSTR + 8 * c8]);
+                            const float4 v1 = *reinterpret_cast<const float4*>(&ew[px * OSTR + 8 * c8 + 4]);
+                            uint4 o;
+                            o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.x, v0.y}, bf16x2));
+                            o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.z, v0.w}, bf16x2));
+                            o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.x, v1.y}, bf16x2));
+                            o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.z, v1.w}, bf16x2));
+                            *reinterpret_cast<uint4*>(d16 + (((size_t)n * a.H + gy) * a.W + gx) * 32 + 8 * c8) = o;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < WPX * 8 / 64; ++j) {
+                        const int f = lane + 64 * j, px = f / 8, c4 = f % 8;
+                        const int gy = wy0 + px / TW, gx = tx0 + px % TW;
+                        if (gy < a.H && gx < a.W)
+                            *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * 32 + 4 * c4) =
+                                *reinterpret_cast<const float4*>(&ew[px * OSTR + 4 * c4]);
+                    }
+                }
+                if (a.pooled != nullptr) {                     // MaxPool2d(2) of the wave's two rows, f32 (its reader rounds after)
+                    const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+                    for (int j = 0; j < (TW / 2) * 8 / 64; ++j) {
+                        const int f = lane + 64 * j, qx = f / 8, c4 = f % 8;
+                        const int gy = (wy0 >> 1), gx = (tx0 >> 1) + qx;
+                        if (gy < Hp && gx < Wp) {
+                            const float* o = &ew[(2 * qx) * OSTR + 4 * c4];
+                            const float4 m = f4max(f4max(*reinterpret_cast<const float4*>(o), *reinterpret_cast<const float4*>(o + OSTR)),
+                                                   f4max(*reinterpret_cast<const float4*>(o + TW * OSTR), *reinterpret_cast<const float4*>(o + TW * OSTR + OSTR)));
+                            *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * 32 + 4 * c4) = m;
+                        }
+                    }
+                }
+            }
+            // (the next tile's epilogue rewrites ew only after this wave's reads: same wave, program order)
+        } else
         // epilogue: LeakyReLU(0.2), NHWC store; per-slot address part in the scalar offset of a buffer store, per-lane part in
         // one VGPR per N-block
         if (a.act16 & 2) {
@@ -449,32 +580,34 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
 }
 
-template <int TW, int WM, int WN, int SRC, bool A16S>
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S>
 static hipError_t launch_k(const ConvArgs& a, unsigned grid, hipStream_t s) {
-    constexpr int BYTES = bf16ws_lds_floats<TW, WM, SRC>() * 4;
+    constexpr int BYTES = bf16ws_lds_floats<TW, WM, MT, NT, SRC>() * 4;
     static DeviceOnce once;
-    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, SRC, A16S>), BYTES, once);
+    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S>), BYTES, once);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, SRC, A16S>), dim3(grid), dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S>), dim3(grid), dim3(512), BYTES, s, a);
     return hipGetLastError();
 }
 
-template <int TW, int WM, int WN, int SRC>
+template <int TW, int WM, int WN, int MT, int NT, int SRC>
 static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
-    return (a.act16 & 1) ? launch_k<TW, WM, WN, SRC, true>(a, grid, s) : launch_k<TW, WM, WN, SRC, false>(a, grid, s);
+    return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false>(a, grid, s);
 }
 
-template <int TW, int WM, int WN>
+template <int TW, int WM, int WN, int MT, int NT>
 static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hipStream_t s) {
-    if (src_mode == SRC_PLAIN) return launch_one<TW, WM, WN, SRC_PLAIN>(a, grid, s);
-    if (src_mode == SRC_POOL && WN == 2) return launch_one<TW, 2, 2, SRC_POOL>(a, grid, s);
-    if (src_mode == SRC_UPCAT && a.Cskip % 32 == 0 && a.Cskip >= 32 && a.Cin - a.Cskip >= 32) return launch_one<TW, WM, WN, SRC_UPCAT>(a, grid, s);
+    if (src_mode == SRC_PLAIN) return launch_one<TW, WM, WN, MT, NT, SRC_PLAIN>(a, grid, s);
+    if constexpr (WN == 2) {
+        if (src_mode == SRC_POOL) return launch_one<TW, WM, WN, MT, NT, SRC_POOL>(a, grid, s);
+    }
+    if (src_mode == SRC_UPCAT && a.Cskip % 32 == 0 && a.Cskip >= 32 && a.Cin - a.Cskip >= 32) return launch_one<TW, WM, WN, MT, NT, SRC_UPCAT>(a, grid, s);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
-    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 || a0.pooled != nullptr ||
-        a0.last_w != nullptr)
+    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 ||
+        ((a0.pooled != nullptr || a0.last_w != nullptr) && p.nt != 1))
         return hipErrorInvalidValue;
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
@@ -484,12 +617,14 @@ hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_
 #endif
     const long total = (long)p.tiles_x * p.tiles_y * a.N * (a.Cout / p.bn);
     const unsigned grid = (unsigned)(total < 256 ? total : 256);     // persistent: one workgroup (8 waves) per CU
-    if (p.wn == 2) {
-        if (p.tw == 32) return launch_src<32, 2, 2>(a, src_mode, grid, s);
-        if (p.tw == 16) return launch_src<16, 2, 2>(a, src_mode, grid, s);
+    if (p.nt == 1) {
+        if (p.tw == 32 && p.mt == 2 && p.wm == 4) return launch_src<32, 4, 1, 2, 1>(a, src_mode, grid, s);
+    } else if (p.wn == 2) {
+        if (p.tw == 32) return launch_src<32, 2, 2, 4, 2>(a, src_mode, grid, s);
+        if (p.tw == 16) return launch_src<16, 2, 2, 4, 2>(a, src_mode, grid, s);
     } else {
-        if (p.tw == 32) return launch_src<32, 4, 1>(a, src_mode, grid, s);
-        if (p.tw == 16) return launch_src<16, 4, 1>(a, src_mode, grid, s);
+        if (p.tw == 32) return launch_src<32, 4, 1, 4, 2>(a, src_mode, grid, s);
+        if (p.tw == 16) return launch_src<16, 4, 1, 4, 2>(a, src_mode, grid, s);
     }
     return hipErrorInvalidValue;
 }

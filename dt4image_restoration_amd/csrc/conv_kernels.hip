@@ -90,6 +90,12 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src
         if (finish() >= 192) { p.ws = 1; return p; }
         p = keep;
     }
+    // ... and the plain 32-channel level-0 layers on its 2 x 1 register tile (same tile as here: 256 pixels x 32 channels); these
+    // run at the HBM roofline of their bf16 tensors either way (measured 0.139 / 0.155 / 0.138 ms against 0.152 / 0.167 / 0.149
+    // here), while up4.conv-0 - two interpolated chunks per 1152-cycle k-loop: producer-bound - and the fused last layer are
+    // faster on this file's kernel (0.52 vs 0.66 ms, 0.14 vs 0.18), so they stay (pnp_capi.hip clears ws for layer 26)
+    if (bf16 && allow_ws && p.splitk == 1 && Cout == 32 && p.tw == 32 && Cin % 32 == 0 && src_mode == SRC_PLAIN && blocks >= 192)
+        p.ws = 1;
     return p;
 }
 

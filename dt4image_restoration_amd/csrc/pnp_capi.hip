@@ -326,6 +326,7 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
                 e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, t2);
             }
             e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, !e->tune.bf16_no_ws);
+            if (li == 26 && e->cplan[li].nt == 1) e->cplan[li].ws = 0;   // up4.conv-2 (fused last layer): see conv3x3_plan
             e->wino[li] = e->wplan[li].use && !bf16;
             if (e->wino[li]) continue;
             const size_t f = conv3x3_partial_floats(e->cplan[li], cfg->n, lh, lw, L.cout);
