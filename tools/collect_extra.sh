@@ -12,3 +12,6 @@ python3 bench.py --mode greedy --no-cpu-baseline > $G/x_greedy.json 2> $G/x_gree
 echo greedy done
 python3 tools/mcts_scale.py > $G/x_mcts.json 2> $G/x_mcts.err
 echo mcts done
+python3 bench.py --convs bf16 --no-greedy > $G/x_bf16_64x256.json 2> $G/x_bf16_64x256.err
+python3 bench.py --convs bf16 --no-greedy --no-cpu-baseline --dump-layers $G/x_layers_bf16_64x256.json > $G/x_bf16_64x256_layers_run.json 2>> $G/x_bf16_64x256.err
+echo bf16-64x256 done
