@@ -62,8 +62,11 @@ typedef struct {
                                     fusion of the last 1x1 layer into the preceding conv's epilogue) */
 #define PNP_FLAG_BF16_CONVS 8    /* BASELINE configs[4]: the 26 conv3x3 layers with Cin >= 32 round their input patch and
                                     weights to bfloat16 (nearest even) and run on v_mfma_f32_32x32x16_bf16 with f32
-                                    accumulation; activations in memory, bias, pooling, upsampling, the first and last
-                                    layer and the k-space stage stay f32.  NOT the reference's arithmetic: parity is
+                                    accumulation; bias, pooling, upsampling, the first and last layer and the k-space
+                                    stage stay f32 (activation tensors between two such layers may be HELD as bf16 -
+                                    rounded once by their producer exactly as the consumer's staging would, so the
+                                    output does not change; such a stage is not readable through pnp_unet_read_stage
+                                    unless the handle has PNP_FLAG_KEEP_STAGES).  NOT the reference's arithmetic: parity is
                                     against the oracle's bf16-operand mode, and the PSNR offset to the f32 path is a
                                     measured, stated bound */
 
@@ -168,7 +171,8 @@ int pnp_profile_layers(pnp_handle h, double* layer_ms, int64_t* layer_launches);
 
 /* Which kernel each of the 28 conv layers runs on for this handle's problem size (fixed at pnp_create):
  * 0 direct MFMA conv, 1 Winograd F(2x2,3x3) MFMA conv (executes 16/36 of the direct multiplies), 4 Winograd F(4x4,3x3)
- * MFMA conv (36/144), 2 VALU first layer, 3 last layer (fused into layer 26's epilogue or its own kernel). */
+ * MFMA conv (36/144), 2 VALU first layer, 3 last layer (fused into layer 26's epilogue or its own kernel), 5 direct bf16
+ * MFMA conv in producer / consumer form (PNP_FLAG_BF16_CONVS handles on chip-filling problems). */
 int pnp_conv_algorithms(pnp_handle h, int32_t* algo28);
 
 /* Engine workspace size in bytes (device memory owned by the handle). */
