@@ -34,6 +34,17 @@ int main() {
                 const ConvPlan cb = conv3x3_plan(n, h, wd, L.cin, L.cout, true);
                 CHECK(cp.tiles_x * cp.tw >= wd && cp.tiles_y * cp.th >= h && cp.splitk >= 1);
                 CHECK(L.cin % cp.ck == 0 && L.cin % cb.ck == 0);
+                // bf16 mode, the producer / consumer plan: only with bf16 operands, always 32-channel chunks and whole tiles, one of its
+                // five tile shapes, never split-K; the f32 plan and the ablation switch never carry it
+                CHECK(cp.ws == 0 && conv3x3_plan(n, h, wd, L.cin, L.cout, true, L.src, false).ws == 0);
+                for (int src : {(int)SRC_PLAIN, (int)L.src}) {
+                    const ConvPlan cw = conv3x3_plan(n, h, wd, L.cin, L.cout, true, src);
+                    if (!cw.ws) continue;
+                    CHECK(cw.ck == 32 && cw.splitk == 1 && cw.tw >= 16 && cw.bm == cw.th * cw.tw && L.cout % cw.bn == 0);
+                    CHECK((cw.mt == 4 && cw.nt == 2 && cw.wm * cw.wn == 4) || (cw.mt == 2 && cw.nt == 1 && cw.wm == 4 && cw.tw == 32 && src == SRC_PLAIN));
+                    CHECK((long)cw.tiles_x * cw.tiles_y * n * (L.cout / cw.bn) >= 192);
+                    CHECK(src != SRC_POOL || cw.wn == 2);
+                }
                 (void)conv3x3_partial_floats(cp, n, h, wd, L.cout);
                 (void)conv3x3_pooled_output_ok(cp);
                 if (&sh != &shapes[0] && &sh != &shapes[3]) continue;     // repack (slow under ASan) for two shapes only
