@@ -1,5 +1,6 @@
-// bf16-operand conv3x3 for gfx950, producer / consumer form (PNP_FLAG_BF16_CONVS, BASELINE configs[4]; the layers with
-// Cout >= 64 on chip-filling problems).  Same arithmetic as conv3x3_mfma_kernel<.., BF16 = true> (conv_kernels.hip): operands
+// bf16-operand conv3x3 for gfx950, producer / consumer form (PNP_FLAG_BF16_CONVS, BASELINE configs[4]; on chip-filling problems
+// every layer but up4.conv-0 and the one carrying the fused last layer - conv3x3_plan() in conv_kernels.hip decides).
+// Same arithmetic as conv3x3_mfma_kernel<.., BF16 = true> (conv_kernels.hip): operands
 // rounded to bf16 (round to nearest even), v_mfma_f32_32x32x16_bf16 with f32 accumulate, f32 bias / LeakyReLU / activations
 // (/root/reference/evaluation/noise.py:88-98 ConvBlock; :22-25 MaxPool2d when the source is pooled while staging).
 //
@@ -14,7 +15,7 @@
 // only fetch, transform and round the next chunk's patch into the other half of a double-buffered LDS patch.  One
 // workgroup barrier per chunk hands a buffer over in each direction:
 //     interval k :  consumers  k-loop(item k-1) from buffer (k-1)&1
-//                   producers  wait loads(k) - write buffer k&1 - issue loads(k+1)
+//                   producers  wait loads(k) - write buffer k&1 - issue loads(k+2) into the register set just freed
 //     barrier #k :  buffer k&1 is complete; buffer (k-1)&1 is free
 // An "item" is one (tile, 32-channel chunk); a workgroup walks tiles blockIdx.x, + gridDim.x, ... (persistent, one per CU),
 // so the producers are already fetching the next tile while the consumers store this one.
