@@ -274,18 +274,40 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                         if (p0 + 32 * k < LH * LW) *reinterpret_cast<float4*>(&lowres[(p0 + 32 * k) * CKL + part * 4]) = raw[k][0];
                     __syncthreads();                           // barrier X: the region is parked (its readers are these four waves)
                     const float* tb = tabs + (meta >> 1) * 4 * (PH + PW);
-#pragma unroll 2
-                    for (int k = 0; k < NIT; ++k) {
-                        if (p0 + 32 * k < PH * PW) {
-                            const float4 rt = *reinterpret_cast<const float4*>(&tb[4 * (pyx[k] >> 16)]);
-                            const float4 ct = *reinterpret_cast<const float4*>(&tb[4 * (PH + (pyx[k] & 0xffff))]);
-                            const float* l0 = &lowres[__float_as_int(rt.x) + part * 4];
-                            const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
-                            const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
-                            store_bf16(buf, k, f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
-                                                       *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
-                                                       ct.z, ct.w, rt.z, rt.w));
+                    // Pieces in groups of G: all table entries, then all source pieces, then the arithmetic and the stores - a piece is
+                    // two dependent LDS round trips (~350 cycles each under the consumers' load), and one piece at a time is 8200
+                    // cycles per item (`profiles/r03_bf16ws_stamps.txt`), nearly twice the consumers' k-loop.  (An LDS store between
+                    // two pieces' reads would serialise them again: the compiler cannot prove patch and region disjoint.)  Pairs
+                    // on the 256-pixel tile (up1/up2.conv-0 -6 %; groups of four: hipcc reuses the registers and gains nothing
+                    // more); the 512-pixel tile has no registers to spare next to its 20-piece raw set.
+                    constexpr int G = NIT <= 12 ? 2 : 1;
+                    constexpr int UNR = (NIT <= 12 || A16S) ? NIT : 2;   // (512-pixel tile, f32 skip tensor: fully unrolled it spills)
+#pragma unroll UNR
+                    for (int k0 = 0; k0 < NIT; k0 += G) {
+                        float4 rt[G], ct[G], q[G][4];
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const int k = k0 + j < NIT ? k0 + j : NIT - 1;
+                            const int yx = pyx[k] >= 0 ? pyx[k] : 0;
+                            rt[j] = *reinterpret_cast<const float4*>(&tb[4 * (yx >> 16)]);
+                            ct[j] = *reinterpret_cast<const float4*>(&tb[4 * (PH + (yx & 0xffff))]);
                         }
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const float* l0 = &lowres[__float_as_int(rt[j].x) + part * 4];
+                            const float* l1 = &lowres[__float_as_int(rt[j].y) + part * 4];
+                            const int c0 = __float_as_int(ct[j].x), c1 = __float_as_int(ct[j].y);
+                            q[j][0] = *reinterpret_cast<const float4*>(l0 + c0);
+                            q[j][1] = *reinterpret_cast<const float4*>(l0 + c1);
+                            q[j][2] = *reinterpret_cast<const float4*>(l1 + c0);
+                            q[j][3] = *reinterpret_cast<const float4*>(l1 + c1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            if (k0 + j < NIT && p0 + 32 * (k0 + j) < PH * PW)
+                                store_bf16(buf, k0 + j, f4lerp2(q[j][0], q[j][1], q[j][2], q[j][3], ct[j].z, ct[j].w, rt[j].z, rt[j].w));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     return;
                 }
