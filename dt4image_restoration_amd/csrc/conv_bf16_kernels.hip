@@ -148,6 +148,15 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
 #ifdef PNP_WS_STAMPS
     int nst = 0;
 #endif
+    // Staggered start.  Persistent workgroups with equal work run in lockstep: the whole chip reads patches, then the whole chip
+    // stores tiles (a store burst at the HBM write peak, `profiles/r03_bf16ws_stamps.txt`).  Sixteen start phases 1536 cycles apart
+    // (blocks b and b + 8 share an XCD: the phase is (b / 8) % 16, so every XCD holds all of them) mix the two kinds of traffic
+    // and leave the NEXT launch's workgroups out of step too; launches of fewer than four tiles per workgroup are too short
+    // to win the skew back (measured: 1-2-tile layers +5 us, the others -3...-8 %, the step -3 %).
+    if (mine >= 4) {
+        const int phase = ((int)blockIdx.x >> 3) & 15;
+        for (int i = 0; i < 3 * phase; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     WS_STAMP(wid >= 4);
     int t = next_live((int)blockIdx.x);
     if (t >= total) return;             // (both roles agree: no barrier is ever reached)
