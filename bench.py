@@ -40,16 +40,19 @@ def mfma_conv_flops(n, h, w):
                    for l in unet_spec.UNET_LAYERS[1:27])
 
 
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
+TRAFFIC_ROUNDS = ("r04", "r03", "r02", "r01")     # newest first
 
 
-def pmc_traffic(n, h, w, which):
+def pmc_traffic(n, h, w, which, mode="f32"):
     """PMC-measured HBM bytes per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 passes of this
-    same command, folded by tools/refresh_profiles.py into profiles/rNN_traffic.json; configs[1] only).
-    which: "conv" (the 26 conv3x3 launches) or "fft" (the three data-fidelity launches).  Returns (bytes, file) or (None, None)."""
-    if (n, h, w) != (64, 256, 256):
-        return None, None
-    for name in TRAFFIC_FILES:
+    same command, folded by tools/refresh_profiles.py into profiles/rNN_traffic[_<n>x<h>x<w>_<mode>].json; the unsuffixed file is
+    configs[1] = 64x256x256 f32).  The file is picked by (n, h, w, mode): a size or mode nobody profiled prints null, never
+    another configuration's bytes.  which: "conv" (the 26 conv3x3 launches) or "fft" (the three data-fidelity launches).
+    Returns (bytes, file) or (None, None)."""
+    names = [f"{r}_traffic_{n}x{h}x{w}_{mode}.json" for r in TRAFFIC_ROUNDS]
+    if (n, h, w, mode) == (64, 256, 256, "f32"):
+        names += [f"{r}_traffic.json" for r in TRAFFIC_ROUNDS]
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -59,6 +62,20 @@ def pmc_traffic(n, h, w, which):
         if kf in t and kw in t:
             return int(t[kf] + t[kw]), "profiles/" + name
     return None, None
+
+
+def g8_reference(h, w, accel, total_iters, mu_tab, sig_tab):
+    """tests/golden/g8_config4.npz - the REFERENCE's own f32 trajectory of configs[4] (2 slices of 512x512, 8x mask, 53
+    iterations of this bench's parameter table) - when this invocation steps exactly that problem; else None."""
+    path = os.path.join(ROOT, "tests", "golden", "g8_config4.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if (h, w) != (512, 512) or float(accel) != float(g["accel"]) or total_iters != g["psnr"].shape[1] or mu_tab.shape[0] < 2:
+        return None
+    if not (np.array_equal(mu_tab[:2], g["mu_tab"]) and np.array_equal(sig_tab[:2], g["sig_tab"])):
+        return None
+    return g["psnr"]
 
 
 def host_cores():
@@ -79,9 +96,11 @@ def host_cores():
     return max(1, min(n, cap))
 
 
-def cpu_baseline(sd_np, h, w, batch, slices, iters, mu_tab, sig_tab, accel=4.0):
+def cpu_baseline(sd_np, h, w, batch, slices, iters, mu_tab, sig_tab, accel=4.0, long_ref_iters=0):
     """Time the CPU oracle (oracle/pnp_oracle.py, torch CPU fp32) on `slices` slices x `iters`
-    iterations of the same workload; scaled linearly to batch-iterations/s."""
+    iterations of the same workload; scaled linearly to batch-iterations/s.  long_ref_iters > 0 (bf16 mode on a problem
+    the committed reference fixture does not cover): also the f32 oracle's per-iteration PSNR of slices 0-1 over that
+    many iterations (untimed; the checker of `psnr_delta_vs_oracle_db`)."""
     from oracle import pnp_oracle as O
     threads = host_cores()
     torch.set_num_threads(threads)
@@ -93,10 +112,15 @@ def cpu_baseline(sd_np, h, w, batch, slices, iters, mu_tab, sig_tab, accel=4.0):
         st, hist = O.run_episode(sd, data, mu_tab[:slices], sig_tab[:slices], iters)
         dt = time.perf_counter() - t0
     slice_iters_per_s = slices * iters / dt
+    long_ref = None
+    if long_ref_iters > 0:
+        two = {k: (v[:2] if k != "mask" else v) for k, v in data.items()}
+        with torch.no_grad():
+            long_ref = O.run_episode(sd, two, mu_tab[:2], sig_tab[:2], long_ref_iters)[1].numpy()
     return {"value": slice_iters_per_s / batch, "unit": "batch-iterations/s", "cores": threads, "kind": "port",
             "sample": f"{slices} slices x {iters} iterations of the {h}x{w} workload in {dt:.1f} s "
                       f"({slice_iters_per_s:.2f} slice-iterations/s), scaled linearly to batch {batch}",
-            "slice_iters_per_s": slice_iters_per_s}, data, hist
+            "slice_iters_per_s": slice_iters_per_s}, data, hist, long_ref
 
 
 def greedy_leg(args, dev, sd_np, n, h, w, world):
@@ -273,17 +297,20 @@ def main():
         # MFMA flops actually ISSUED: a Winograd F(2x2,3x3) layer multiplies 16 instead of 36 times per 2x2 outputs, an
         # F(4x4,3x3) layer 36 instead of 144 per 4x4 outputs
         ratio = {0: 1.0, 1: 16.0 / 36.0, 4: 36.0 / 144.0}
-        exec_step = n * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * ratio.get(algos[l.index], 1.0)
-                            for l in unet_spec.UNET_LAYERS[1:27])
+        # bf16 mode: a weight rides as `terms` bf16 terms (2 = hi + lo, the default), one MFMA each per k-step
+        terms = eng.bf16_weight_terms() if bf16 else 1
+        exec_step = n * terms * sum(2 * l.macs_per_out_pixel * (h >> l.level) * (w >> l.level) * ratio.get(algos[l.index], 1.0)
+                                    for l in unet_spec.UNET_LAYERS[1:27])
         executed = exec_step * steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
-        # the PMC traffic files are passes of the default (f32) command: no figure for the bf16-operand mode
-        conv_traffic, conv_traffic_src = (None, None) if bf16 else pmc_traffic(n, h, w, "conv")
+        mode = "bf16" if bf16 else "f32"
+        conv_traffic, conv_traffic_src = pmc_traffic(n, h, w, "conv", mode)
         ms_all = sorted(1e3 * t / steps for t in times)
         out = {
             "metric": "pnp_admm_iterations_per_sec", "value": round(value, 4), "unit": "batch-iterations/s",
             "n_gpus": world, "world_size_reported_by_rccl": (dist.get_world_size() if dist is not None else None), "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 conv operands, f32 accumulate / activations / k-space" if bf16 else "f32", "data": "synthetic",
+            "dtype": (f"bf16 conv operands (weights as {terms} bf16 term{'s hi + lo' if terms == 2 else ''}), f32 accumulate / bias / "
+                      "pooling / upsampling / k-space") if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"{'configs[4] geometry' if bf16 else 'configs[1]'}: {h}x{w} CS-MRI slices, batch {n} per GPU, "
                                    f"U-Net denoiser{' (bf16 conv operands)' if bf16 else ''} + FFT prox, "
                                    f"seeded per-slice (mu, sigma) table, {args.accel:g}x radial mask", "slices_per_gpu": n,
@@ -328,8 +355,8 @@ def main():
             out["roofline_fft"] = {
                 "kernel": "fft_rows_kernel<1> + fft_cols_kernel<1> + fft_rows_kernel<2> (3 launches/step)", "bound": "hbm",
                 "achieved": round(alg / (fft_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, h, w, "fft")[0],
-                "traffic_source": pmc_traffic(n, h, w, "fft")[1],
+                "frac": round(alg / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, h, w, "fft", mode)[0],
+                "traffic_source": pmc_traffic(n, h, w, "fft", mode)[1],
                 "bytes_per_step": int(alg), "kernel_ms_per_step": round(fft_ms, 4),
                 "moved_gbs": round(moved / (fft_ms * 1e-3) / 1e9, 1),
                 "note": "achieved = algorithmic 37 B/px (x 4 + u 8 + y0 8 + mask 1 read, z 8 + u 8 written) / kernel time; the "
@@ -357,19 +384,39 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             args.cpu_slices = min(args.cpu_slices, n)              # the sample is a prefix of the batch
             mu_c, sg_c = synthetic.param_table(n, total_iters, seed=77)
-            cb, cdata, chist = cpu_baseline(sd_np, h, w, n, args.cpu_slices, args.cpu_iters, mu_c, sg_c, args.accel)
+            g8 = g8_reference(h, w, args.accel, total_iters, mu_tab, sig_tab) if bf16 else None
+            cb, cdata, chist, long_ref = cpu_baseline(sd_np, h, w, n, args.cpu_slices, args.cpu_iters, mu_c, sg_c, args.accel,
+                                                      long_ref_iters=total_iters if (bf16 and g8 is None and n >= 2) else 0)
             # PSNR delta vs the oracle ON THE TIMED HANDLE (same tile plan, same launches as the timed region): reset it, run the
             # oracle's parameter prefix over all n slices, compare the sampled slices (the oracle's data are a prefix of this batch)
             assert np.array_equal(cdata["gt"], data["gt"][:args.cpu_slices]) and np.array_equal(mu_c, mu_tab)
             x2, z2, u2 = eng.reset(x0, y0, mask)
-            for t in range(args.cpu_iters):
+            gpu_hist = []
+            for t in range(total_iters if bf16 else args.cpu_iters):
                 eng.step(x2, z2, u2, mu_d[t], sg_d[t])
-            dpsnr = (eng.psnr(x2, gt).cpu()[:args.cpu_slices] - chist[:, -1]).abs().max()
+                gpu_hist.append(eng.psnr(x2, gt))
+            gpu_hist = torch.stack(gpu_hist, dim=1).cpu()          # [n, iterations]
             cb.pop("slice_iters_per_s")
             out["cpu_baseline"] = cb
-            out["psnr_delta_vs_oracle_db"] = float(dpsnr)          # the oracle here is always the f32 reference arithmetic
-            out["psnr_delta_what"] = (f"max over the first {args.cpu_slices} slices after {args.cpu_iters} iterations, computed on the TIMED "
-                                      f"{n}-slice handle (same plan and kernels as the timed region) against the f32 CPU oracle")
+            if not bf16:
+                dpsnr = (gpu_hist[:args.cpu_slices, args.cpu_iters - 1] - chist[:, -1]).abs().max()
+                out["psnr_delta_vs_oracle_db"] = float(dpsnr)      # the oracle here is always the f32 reference arithmetic
+                out["psnr_delta_what"] = (f"max over the first {args.cpu_slices} slices after {args.cpu_iters} iterations, computed on the TIMED "
+                                          f"{n}-slice handle (same plan and kernels as the timed region) against the f32 CPU oracle")
+            else:
+                # bf16 mode: the offset to the f32 reference GROWS with the iteration count, so it is evaluated at the LAST timed
+                # iteration (warm-up + steps), against the reference's own trajectory where this invocation steps the committed
+                # fixture's problem (tests/golden/g8_config4.npz), else against the f32 CPU oracle run that long on two slices
+                ref, src = g8, "the reference's own f32 trajectory, tests/golden/g8_config4.npz"
+                if ref is None:
+                    ref, src = long_ref, "the f32 CPU oracle stepped over the same iterations"
+                d = np.abs(gpu_hist[:ref.shape[0]].numpy() - ref)
+                out["psnr_delta_vs_oracle_db"] = float(d[:, -1].max())
+                out["psnr_delta_max_over_iterations_db"] = float(d.max())
+                marks = sorted({0, 5, 9, 19, 29, 39, total_iters - 4, total_iters - 1} & set(range(total_iters)))
+                out["psnr_delta_by_iteration_db"] = {str(m + 1): round(float(d[:, m].max()), 5) for m in marks}
+                out["psnr_delta_what"] = (f"max over slices 0-{ref.shape[0] - 1} at the LAST iteration ({total_iters} = warm-up + timed steps) and per "
+                                          f"iteration count, computed on the TIMED {n}-slice handle against {src}; north_star's bound is 0.01 dB")
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

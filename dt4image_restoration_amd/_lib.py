@@ -47,6 +47,7 @@ SIGNATURES = {
     "pnp_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pnp_profile_layers": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pnp_conv_algorithms": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "pnp_bf16_weight_terms": (C.c_int, [C.c_void_p]),
     "pnp_workspace_bytes": (C.c_size_t, [C.c_void_p]),
 }
 

@@ -55,13 +55,19 @@ constexpr int bf16ws_lds_floats() {
 // or 512 x 64 for Cout = 64), 2 x 1 for the 32-channel level-0 layers (256 x 32; HBM-bound even on bf16 tensors, so its
 // epilogue goes through LDS for 16-B stores, the pooled copy of the next stage and the fused last layer, as in
 // conv_kernels.hip).
-template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S>
+//
+// NW: bf16 terms per weight.  2 (the mode's default): every k-step multiplies its A fragments by the weight's hi AND lo term
+// (pack_conv3x3_weights_bf16: hi = bf16(w), lo = bf16(w - hi), 1 KiB each per k-step and N-block, hi first), 2 x MT x NT MFMAs into
+// the same accumulators - the convolution with the 16-bit-mantissa weight hi + lo.  1: PNP_BF16_W1, the round-3 arithmetic.
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW>
 __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     constexpr int CK = 32;
     constexpr int KS = 9 * (CK / 16);   // k-steps (16 channels) per chunk
-    // weight fragments in flight, k-steps ahead (divides KS: k-step j sits in slot j % PFD): 6 x 256 MFMA cycles for the 4 x 2
-    // tile; the 2 x 1 tile's k-step is 64 cycles, it keeps a whole chunk ahead
-    constexpr int PFD = MT * NT >= 8 ? 6 : 18;
+    constexpr int KB = NW * 1024;       // bytes of one k-step of one N-block in the weight stream
+    // weight fragments in flight, k-steps ahead (divides KS: k-step j sits in slot j % PFD): 1536 MFMA cycles for the 4 x 2 tile
+    // (6 k-steps of 8 MFMAs, 3 of 16 with two-term weights); the 2 x 1 tile's k-step is 64 (128) cycles, it keeps a whole
+    // chunk (half a chunk) ahead
+    constexpr int PFD = (MT * NT >= 8 ? 6 : 18) / NW;
     static_assert(KS % PFD == 0 && WM * WN == 4, "ring / wave grid");
     static_assert(NT == 2 || (NT == 1 && WN == 1 && TW == 32 && MT == 2), "32-channel tile: a wave owns two whole tile rows");
     constexpr int CKP = (CK + 8) / 2;   // patch pixel stride in floats (CK + 8 halves: b128 lane groups on distinct banks)
@@ -400,21 +406,23 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     // case is what keeps it free of spills - hipcc unswitches the 144-MFMA body on it and then runs out of registers.)
     // Weight fragments come through a buffer descriptor: the lane part of the address (lane * 16 B) is one VGPR for good and
     // everything else - tile, N-block, chunk, k-step - is scalar arithmetic in the instruction's soffset.
-    const size_t wbytes = ((size_t)(a.Cout / 32) * nchunks * KS + 16) * 1024;      // the pack ends in 16 zero k-steps
+    const size_t wbytes = ((size_t)(a.Cout / 32) * nchunks * KS + 16) * KB;        // the pack ends in 16 zero k-steps
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, (int)wbytes, 0x00020000);
     const int wlane = lane * 16;
-    const int wstride = nchunks * KS * 1024;                                       // bytes between N-blocks
+    const int wstride = nchunks * KS * KB;                                         // bytes between N-blocks
     auto wbase = [&](int tt) {          // byte offset of the weight stream of tile tt, this wave's N-block 0
         return (fdiv(tt, tilesM, r_tilesM) * (WN * NT) + wn * NT) * wstride;
     };
     auto wload = [&](int soff) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, soff, 0)); };
-    float4 bq[PFD][NT];
+    float4 bq[PFD][NT][NW];
     float bias_v[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         bias_v[nt] = a.bias[(fdiv(t, tilesM, r_tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
 #pragma unroll
-        for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wbase(t) + nt * wstride + p * 1024);
+        for (int p = 0; p < PFD; ++p)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) bq[p][nt][w] = wload(wbase(t) + nt * wstride + p * KB + w * 1024);
     }
     int g = 0;
     WS_STAMP(0);
@@ -438,10 +446,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             WS_STAMP(0);
             const bool park = UP2 && c + 1 < nchunks && c + 1 >= nskip;   // the producers park a low-res region during this k-loop
             const float* pb = patch + (g & 1) * PATCH;
-            const int wc = wtile + c * (KS * 1024);            // this chunk's k-step 0
-            // the 2 x 1 tile keeps a whole chunk of fragments ahead, refilled in place: past the tile's last chunk the stream goes on
-            // with the next tile's first (few registers here, and its short epilogue would not cover a re-prime)
-            const int wfollow = (NT == 1 && c + 1 == nchunks) ? wbase(t_next < total ? t_next : t) : wc + KS * 1024;
+            const int wc = wtile + c * (KS * KB);              // this chunk's k-step 0
+            // the 2 x 1 tile's ring runs on past the tile's last chunk into the next tile's first, refilled in place (few registers
+            // here, and its short epilogue would not cover a re-prime); the 4 x 2 tile's runs on into whatever follows the chunk
+            // and is re-primed after the tile's last k-loop
+            const int wfollow = (NT == 1 && c + 1 == nchunks) ? wbase(t_next < total ? t_next : t) : wc + KS * KB;
             float4 a0[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&pb[aoff[mt]]);
@@ -457,16 +466,20 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int w = 0; w < NW; ++w)                   // hi, then lo: an accumulator comes round again MT * NT MFMAs later
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
-                                                                              __builtin_bit_cast(bf16x8, bq[ks % PFD][nt]), acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
+                                                                                  __builtin_bit_cast(bf16x8, bq[ks % PFD][nt][w]), acc[mt][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // refill the slot just read with k-step ks + PFD of the stream
+                // refill the slot just read with k-step ks + PFD of the stream (this chunk's, or the following chunk's first ones)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bq[ks % PFD][nt] = wload((NT == 1 ? wfollow + (ks + PFD - KS) * 1024 : wc + (ks + PFD) * 1024) + nt * wstride);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w)
+                        bq[ks % PFD][nt][w] = wload((ks + PFD < KS ? wc + (ks + PFD) * KB : wfollow + (ks + PFD - KS) * KB) + nt * wstride + w * 1024);
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
@@ -481,7 +494,9 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 bias_v[nt] = a.bias[(fdiv(t_next, tilesM, r_tilesM) * (WN * NT) + wn * NT + nt) * 32 + li];
                 if constexpr (NT != 1) {
 #pragma unroll
-                    for (int p = 0; p < PFD; ++p) bq[p][nt] = wload(wn0 + nt * wstride + p * 1024);
+                    for (int p = 0; p < PFD; ++p)
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) bq[p][nt][w] = wload(wn0 + nt * wstride + p * KB + w * 1024);
                 }
             }
         }
@@ -612,19 +627,21 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
 }
 
-template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S>
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW>
 static hipError_t launch_k(const ConvArgs& a, unsigned grid, hipStream_t s) {
     constexpr int BYTES = bf16ws_lds_floats<TW, WM, MT, NT, SRC>() * 4;
     static DeviceOnce once;
-    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S>), BYTES, once);
+    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW>), BYTES, once);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S>), dim3(grid), dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW>), dim3(grid), dim3(512), BYTES, s, a);
     return hipGetLastError();
 }
 
 template <int TW, int WM, int WN, int MT, int NT, int SRC>
 static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
-    return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false>(a, grid, s);
+    if (a.bf16 == 2)
+        return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 2>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 2>(a, grid, s);
+    return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 1>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 1>(a, grid, s);
 }
 
 template <int TW, int WM, int WN, int MT, int NT>
@@ -638,7 +655,7 @@ static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hip
 }
 
 hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
-    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 ||
+    if (!p.ws || p.ck != 32 || a0.Cin % 32 != 0 || a0.Cout % p.bn != 0 || !a0.bf16 || !conv3x3_tensor_fits(a0.N, a0.H, a0.W, a0.Cin, a0.Cout) ||
         ((a0.pooled != nullptr || a0.last_w != nullptr) && p.nt != 1))
         return hipErrorInvalidValue;
     ConvArgs a = a0;

@@ -119,9 +119,12 @@ void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* d
     for (int i = 0; i < 1024; ++i) dst[o++] = 0.f;
 }
 
-// bf16 variant (PNP_FLAG_BF16_CONVS): 16-byte units [cout/32][cin/ck][tap 9][s ck/16][lane 64]; lane l (n = l&31, h = l>>5)
-// holds W[32*cb + n][ck*chunk + 16*s + 8*h + j][ky][kx], j = 0..7, rounded to bf16 (round to nearest even): the B operand
-// of v_mfma_f32_32x32x16_bf16 for k-step (chunk, tap, s).  Same float count bound as the f32 pack (half of it used).
+// bf16 variant (PNP_FLAG_BF16_CONVS): 16-byte units [cout/32][cin/ck][tap 9][s ck/16][term][lane 64]; lane l (n = l&31, h = l>>5)
+// holds W[32*cb + n][ck*chunk + 16*s + 8*h + j][ky][kx], j = 0..7: the B operand of v_mfma_f32_32x32x16_bf16 for k-step
+// (chunk, tap, s).  terms = 1: the weight rounded to bf16 (nearest even).  terms = 2 (the mode's default): TWO bf16 terms per
+// weight, hi = bf16(w) and lo = bf16(w - hi), 1 KiB each per k-step, hi first - the k-loop multiplies the same activation fragment
+// by both and accumulates both products in f32, i.e. it convolves with the 16-bit-mantissa weight hi + lo: the fixed 2^-8
+// perturbation of the network that one-term weights are - 0.015 dB of PSNR drift over configs[4]'s 50 iterations - becomes 2^-16.
 static inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -129,20 +132,33 @@ static inline uint16_t f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, float* dst_f) {
+static inline float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+constexpr int kBf16TailSteps = 16;                        // zero k-steps behind the last stream: the fragment rings read ahead (PFD <= 9)
+size_t conv3x3_pack_floats_bf16(int cin, int cout, int terms) {
+    return ((size_t)(cout / 32) * (cin / 16) * 9 + kBf16TailSteps) * 256 * terms;
+}
+void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, int terms, float* dst_f) {
     uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
     size_t o = 0;
     for (int cb = 0; cb < cout / 32; ++cb)
         for (int ch = 0; ch < cin / ck; ++ch)
             for (int tap = 0; tap < 9; ++tap)
                 for (int s = 0; s < ck / 16; ++s)
-                    for (int l = 0; l < 64; ++l)
-                        for (int j = 0; j < 8; ++j) {
-                            const int co = 32 * cb + (l & 31);
-                            const int ci = ck * ch + 16 * s + 8 * (l >> 5) + j;
-                            dst[o++] = f32_to_bf16_rne(oihw[((size_t)co * cin + ci) * 9 + tap]);
-                        }
-    for (int i = 0; i < 8192; ++i) dst[o++] = 0;          // 16 k-steps of zeros for the prefetch tail (PFD <= 9)
+                    for (int term = 0; term < terms; ++term)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = 32 * cb + (l & 31);
+                                const int ci = ck * ch + 16 * s + 8 * (l >> 5) + j;
+                                const float w = oihw[((size_t)co * cin + ci) * 9 + tap];
+                                const uint16_t hi = f32_to_bf16_rne(w);
+                                dst[o++] = term == 0 ? hi : f32_to_bf16_rne(w - bf16_to_f32(hi));   // (w - hi is exact in f32)
+                            }
+    for (size_t i = 0; i < (size_t)kBf16TailSteps * 512 * terms; ++i) dst[o++] = 0;
 }
 
 // One workgroup (4 waves) = one TH x TW pixel tile of one slice x BN output channels; wave (wm, wn) owns a
@@ -163,8 +179,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // producing launch, rounded once with the same round-to-nearest-even the staging would apply - the patch gets the same
 // bits, half the HBM bytes) and so does dst unless a.act16 says f32 (the layer in front of the unfused 1x1 conv).  The
 // pooled copy and the low-res source of the upsample stay f32: their consumers round AFTER max / interpolation.
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK, bool BF16, bool A16>
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, int WPS, bool SPLITK, int BF16, bool A16>
 __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a) {
+    constexpr int NW = BF16 == 2 ? 2 : 1;   // bf16 terms per weight (pack_conv3x3_weights_bf16): NW MFMAs per (M-block, N-block, k-step)
     static_assert(!A16 || (BF16 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL), "bf16 activations: level-0 plan only");
     // padded pixel stride in LDS (floats): b128 lane groups hit 16 distinct slots (f32: CK + 4; bf16: CK + 8 halves)
     constexpr int CKP = BF16 ? (CK + 8) / 2 : CK + 4;
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cb = cbt * (WN * NT) + wn * NT + nt;
-        bptr[nt] = reinterpret_cast<const float4*>(a.wpack) + ((size_t)cb * nchunks_all + c_begin) * KS * 64 + lane;
+        bptr[nt] = reinterpret_cast<const float4*>(a.wpack) + ((size_t)cb * nchunks_all + c_begin) * KS * 64 * NW + lane;
         const float bias = SPLITK ? 0.f : a.bias[cb * 32 + li];    // accumulators start at the bias
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -382,11 +399,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 
     // B fragments (weights, pre-packed per lane, L2-resident) run PFD k-steps ahead: slot ks % PFD is refilled with
     // k-step ks + PFD right after the MFMAs of k-step ks; an f32 k-step is 1000-4000 cycles of MFMA issue.
-    float4 bq[PFD][NT];
+    float4 bq[PFD][NT][NW];
 #pragma unroll
     for (int p = 0; p < PFD; ++p)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[p][nt] = bptr[nt][p * 64];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) bq[p][nt][w] = bptr[nt][(p * NW + w) * 64];
 
     for (int c = c_begin; c < c_end; ++c) {
         if (c > c_begin) __syncthreads();      // every wave is done reading the previous chunk's patch
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 
         const float4* bp[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bp[nt] = bptr[nt] + (size_t)(c - c_begin) * KS * 64;
+        for (int nt = 0; nt < NT; ++nt) bp[nt] = bptr[nt] + (size_t)(c - c_begin) * KS * 64 * NW;
         float4 a0[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const float4*>(&patch[aoff[mt]]);
@@ -428,14 +447,16 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             __builtin_amdgcn_sched_barrier(0);
 #define PNP_MFMA_ROUND(comp)                                                                                     \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)          \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].comp, bq[ks % PFD][nt].comp, acc[mt][nt], 0, 0, 0);
-            if constexpr (BF16) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].comp, bq[ks % PFD][nt][0].comp, acc[mt][nt], 0, 0, 0);
+            if constexpr (BF16 != 0) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int w = 0; w < NW; ++w)               // (hi, then lo: the same accumulator comes round again MT * NT MFMAs later)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
-                                                                              __builtin_bit_cast(bf16x8, bq[ks % PFD][nt]), acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
+                                                                                  __builtin_bit_cast(bf16x8, bq[ks % PFD][nt][w]), acc[mt][nt], 0, 0, 0);
             } else {
             PNP_MFMA_ROUND(x)
             PNP_MFMA_ROUND(y)
@@ -445,7 +466,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
 #undef PNP_MFMA_ROUND
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[ks % PFD][nt] = bp[nt][(ks + PFD) * 64];   // refill the slot just read
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) bq[ks % PFD][nt][w] = bp[nt][((ks + PFD) * NW + w) * 64];   // refill the slot just read
             if (ks + 1 < KS) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a0[mt] = a1[mt];
@@ -574,14 +597,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, bool BF16>
+template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, int BF16>
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
     // (the UPCAT variant also holds the low-res source region in LDS and a prefetched skip chunk in registers: two
     // workgroups per CU; three with the bf16 patch measured 8 % slower on up4.conv-0, it spills 54 registers)
     constexpr int WPS = (MT * NT <= 2 && SRC != SRC_UPCAT) ? 3 : (MT * NT <= 8 ? 2 : 1);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
-    constexpr bool CAN16 = BF16 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL;
+    constexpr bool CAN16 = BF16 != 0 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL;
     if constexpr (CAN16) {
         if (a.act16 & 1) {
             hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16, true>), grid, dim3(256), 0, s, a);
@@ -593,7 +616,7 @@ static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t 
     return hipGetLastError();
 }
 
-template <int TW, int MT, int NT, int WM, int WN, int CK, bool SPLITK, bool BF16>
+template <int TW, int MT, int NT, int WM, int WN, int CK, bool SPLITK, int BF16>
 static hipError_t launch_cfg(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
     switch (src_mode) {
         case SRC_PLAIN: return launch_inst<TW, MT, NT, WM, WN, CK, SRC_PLAIN, SPLITK, BF16>(a, p, s);
@@ -603,35 +626,39 @@ static hipError_t launch_cfg(const ConvArgs& a, const ConvPlan& p, int src_mode,
     }
 }
 
-template <int TW, bool BF16>
+template <int TW, int BF16>
 static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
     if (p.mt == 2 && p.wn == 4) return launch_cfg<TW, 2, 1, 1, 4, 32, true, BF16>(a, p, src_mode, s);    // small problems
     if (p.mt == 2 && p.wn == 2) return launch_cfg<TW, 2, 1, 2, 2, 32, true, BF16>(a, p, src_mode, s);
     if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32, false, BF16>(a, p, src_mode, s);
     if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16, false, BF16>(a, p, src_mode, s);
     if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32, false, BF16>(a, p, src_mode, s);
-    if constexpr (BF16) return hipErrorInvalidValue;       // the bf16 plan never picks the 256-accumulator tile
-    else return launch_cfg<TW, 4, 4, 2, 2, 32, false, false>(a, p, src_mode, s);
+    if constexpr (BF16 != 0) return hipErrorInvalidValue;  // the bf16 plan never picks the 256-accumulator tile
+    else return launch_cfg<TW, 4, 4, 2, 2, 32, false, 0>(a, p, src_mode, s);
 }
 
 hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, hipStream_t s) {
     if (a0.Cin % 32 != 0 || a0.Cout % 32 != 0 || (a0.Cout > 64 && a0.Cout % 128 != 0)) return hipErrorInvalidValue;
+    if (!conv3x3_tensor_fits(a0.N, a0.H, a0.W, a0.Cin, a0.Cout)) return hipErrorInvalidValue;
     if (p.ws) return launch_conv3x3_bf16ws(a0, p, src_mode, s);
-    const bool bf16 = a0.bf16 != 0;
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
     const bool split = p.mt == 2 && p.wn >= 2;           // the small-problem configs always go through the workspace
     if (split && a.partial == nullptr) return hipErrorInvalidValue;
     hipError_t e;
-    if (bf16) {
-        if (p.tw == 32) e = launch_tw<32, true>(a, p, src_mode, s);
-        else if (p.tw == 16) e = launch_tw<16, true>(a, p, src_mode, s);
-        else e = launch_tw<8, true>(a, p, src_mode, s);
+    if (a.bf16 == 2) {                                    // bf16 operands, two-term weights (the mode's default)
+        if (p.tw == 32) e = launch_tw<32, 2>(a, p, src_mode, s);
+        else if (p.tw == 16) e = launch_tw<16, 2>(a, p, src_mode, s);
+        else e = launch_tw<8, 2>(a, p, src_mode, s);
+    } else if (a.bf16 == 1) {                             // PNP_BF16_W1: one-term weights (round-3 arithmetic, ablation)
+        if (p.tw == 32) e = launch_tw<32, 1>(a, p, src_mode, s);
+        else if (p.tw == 16) e = launch_tw<16, 1>(a, p, src_mode, s);
+        else e = launch_tw<8, 1>(a, p, src_mode, s);
     } else {
-        if (p.tw == 32) e = launch_tw<32, false>(a, p, src_mode, s);
-        else if (p.tw == 16) e = launch_tw<16, false>(a, p, src_mode, s);
-        else e = launch_tw<8, false>(a, p, src_mode, s);
+        if (p.tw == 32) e = launch_tw<32, 0>(a, p, src_mode, s);
+        else if (p.tw == 16) e = launch_tw<16, 0>(a, p, src_mode, s);
+        else e = launch_tw<8, 0>(a, p, src_mode, s);
     }
     if (e != hipSuccess || !split) return e;
     const size_t plane4 = (size_t)a.N * a.H * a.W * a.Cout / 4;
@@ -640,6 +667,14 @@ hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, h
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bias, a.dst, a.tact, plane4,
                        p.splitk, a.Cout / 4, (size_t)a.H * a.W * a.Cout / 4);
     return hipGetLastError();
+}
+
+// The direct kernels address a whole activation tensor through ONE buffer descriptor (32-bit num_records, 32-bit byte offsets):
+// an OUTPUT tensor of 2 GiB or more would wrap them - refused here and, with a message, by pnp_create.  (The F(4x4) kernels use a
+// descriptor per slice.)
+bool conv3x3_tensor_fits(int N, int H, int W, int Cin, int Cout) {
+    (void)Cin;                                             // (sources: per-slice descriptors / 64-bit pointers)
+    return (size_t)N * H * W * (size_t)Cout * 4 < ((size_t)1 << 31);
 }
 
 // The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
@@ -667,6 +702,7 @@ Tuning tuning_from_env() {
     if (const char* v = getenv("PNP_WINO_F4_ORDER")) t.f4_order = atoi(v) != 0;
     t.bf16_f32_acts = getenv("PNP_BF16_F32_ACTS") != nullptr;
     t.bf16_no_ws = getenv("PNP_BF16_NO_WS") != nullptr;
+    t.bf16_w1 = getenv("PNP_BF16_W1") != nullptr;
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;
 }

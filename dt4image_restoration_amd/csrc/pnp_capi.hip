@@ -91,6 +91,7 @@ struct pnp_engine {
     bool fuse_last = false;           // last 1x1 layer rides in the epilogue of up4.conv-2
     bool fuse_first = false;          // first layer (2 -> 32) is computed in the staging of inc.conv-1 (F(4x4) 32-channel variant)
     bool pool_ok[4] = {};             // level k's stage output also gets a pooled copy (its producing kernel supports it)
+    int bf16_terms = 0;               // bf16 mode: bf16 terms per conv weight (2: hi + lo, the default; 1: PNP_BF16_W1); 0 = f32 mode
     bool act16 = false;               // bf16 mode: the 32-channel level-0 activations (lv[0].p/q/s) are stored as bf16 (ConvArgs.act16)
     uint8_t abits[N_LAYERS] = {};     // bf16 mode, per conv layer: ConvArgs.act16 (bit 0: src0 holds bf16, bit 1: dst holds bf16)
     // data-fidelity stage
@@ -174,7 +175,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         ConvArgs a{};
         a.pooled = pooled;
         a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
-        a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
+        a.bf16 = e->bf16_terms;
         a.act16 = e->abits[li];
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
         if (L.src == SRC_UPCAT) {
@@ -223,7 +224,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         const LayerSpec& L = kLayers[26];
         ConvArgs a{};
         a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
-        a.bf16 = (e->cfg.flags & PNP_FLAG_BF16_CONVS) ? 1 : 0;
+        a.bf16 = e->bf16_terms;
         a.act16 = e->abits[26] & 1;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
@@ -272,7 +273,7 @@ int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float
 extern "C" {
 
 const char* pnp_last_error(void) { return g_err.c_str(); }
-const char* pnp_version(void) { return "pnpadmm 0.3 (gfx950, f32 MFMA; optional bf16-operand convs)"; }
+const char* pnp_version(void) { return "pnpadmm 0.4 (gfx950, f32 MFMA; optional bf16-operand convs with two-term weights)"; }
 
 // Does layer `li` (a stage's last conv, planned already) also write the 2x2 max-pooled copy of its output?  Its output must have
 // even sides and its kernel must support it (a Winograd kernel, or the direct kernel's LDS-epilogue plan).  ONE predicate for the
@@ -288,6 +289,7 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
     e->tune = tuning_from_env();
     const size_t N = cfg->n, H = cfg->h, W = cfg->w;
     const bool bf16 = (cfg->flags & PNP_FLAG_BF16_CONVS) != 0;
+    e->bf16_terms = bf16 ? (e->tune.bf16_w1 ? 1 : 2) : 0;
     static const int chan[5] = {32, 64, 128, 256, 512};
     for (int k = 0; k < 5; ++k) {
         LevelBufs& L = e->lv[k];
@@ -328,6 +330,10 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, !e->tune.bf16_no_ws);
             if (li == 26 && e->cplan[li].nt == 1) e->cplan[li].ws = 0;   // up4.conv-2 (fused last layer): see conv3x3_plan
             e->wino[li] = e->wplan[li].use && !bf16;
+            if (e->wino[li] && e->wplan[li].algo == 4) continue;          // (per-slice descriptors)
+            if (!conv3x3_tensor_fits(cfg->n, lh, lw, L.cin, L.cout))
+                return fail(PNP_ERR_INVALID, "pnp_create: layer %d's output tensor (%d x %d x %d x %d floats) reaches 2 GiB, past this "
+                            "kernel's buffer descriptor: use a smaller batch per handle", li, cfg->n, lh, lw, L.cout);
             if (e->wino[li]) continue;
             const size_t f = conv3x3_partial_floats(e->cplan[li], cfg->n, lh, lw, L.cout);
             if (f > pf) pf = f;
@@ -369,7 +375,7 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             }
             for (int li = 1; li <= 26; ++li) {
                 bool in16;
-                if (li == 3) in16 = false;                          // down1.conv-0 reads the f32 pooled copy of level 0
+                if (kLayers[li].src == SRC_POOL && e->pool_ok[kLayers[li].level - 1]) in16 = false;   // reads the producer's f32 pooled copy (today: li = 3)
                 else if (li == 15 || li == 18 || li == 21 || li == 24) in16 = out16[li == 15 ? 11 : (li == 18 ? 8 : (li == 21 ? 5 : 2))];
                 else in16 = out16[li - 1];
                 // the level-0 kernel writes bf16 only from its bf16-source variant
@@ -433,6 +439,7 @@ int pnp_destroy(pnp_handle e) {
 }
 
 size_t pnp_workspace_bytes(pnp_handle e) { return e ? e->ws_bytes : 0; }
+int pnp_bf16_weight_terms(pnp_handle e) { return e ? e->bf16_terms : 0; }
 
 // All-or-nothing: every layer is packed on the host and uploaded into NEW device buffers first; the handle's buffers are
 // replaced only when all 56 uploads succeeded, so a failure leaves the handle exactly as it was (an earlier successful
@@ -474,9 +481,9 @@ int pnp_load_unet_weights(pnp_handle e, const float* blob, size_t n_floats) {
                 pack_winograd_weights(w, L.cin, L.cout, e->wplan[li].ck, tmp.data());
                 src = tmp.data();
             } else {
-                pf = conv3x3_pack_floats(L.cin, L.cout);
+                pf = bf16 ? conv3x3_pack_floats_bf16(L.cin, L.cout, e->bf16_terms) : conv3x3_pack_floats(L.cin, L.cout);
                 tmp.assign(pf, 0.f);
-                if (bf16) pack_conv3x3_weights_bf16(w, L.cin, L.cout, e->cplan[li].ck, tmp.data());
+                if (bf16) pack_conv3x3_weights_bf16(w, L.cin, L.cout, e->cplan[li].ck, e->bf16_terms, tmp.data());
                 else pack_conv3x3_weights(w, L.cin, L.cout, e->cplan[li].ck, tmp.data());
                 src = tmp.data();
             }

@@ -25,6 +25,8 @@ struct Tuning {
                                   // 64-channel-block layer on 16-tile M-blocks
     bool bf16_no_ws = false;      // PNP_BF16_NO_WS (ablation): bf16 mode without the producer / consumer kernel (the round-2 kernel everywhere)
     bool bf16_f32_acts = false;   // PNP_BF16_F32_ACTS (ablation): bf16 mode keeps every activation in f32, as rounds 1-2 did
+    bool bf16_w1 = false;         // PNP_BF16_W1 (ablation): bf16 mode with ONE bf16 term per weight (the round-3 arithmetic: 0.015 dB of
+                                  // PSNR drift against the f32 reference over configs[4]'s 50 iterations) instead of hi + lo
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
@@ -65,7 +67,8 @@ struct ConvArgs {
     int Cin, Cskip, Cout;
     int tilesX, tilesY;  // filled by launch_conv3x3 from the plan
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
-    int bf16;            // direct kernel: bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate
+    int bf16;            // bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate: 0 = off, 2 = weights as two bf16 terms
+                         // hi + lo (the mode's default), 1 = one term (PNP_BF16_W1)
     int act16;           // bf16 mode, 32-channel plan: bit 0 = src0 (PLAIN source / UPCAT skip) holds bf16, 2 B per channel; bit 1 = dst too
     int order;           // F(4x4): blockIdx -> tile order (wino4_decode), from the plan
 #ifdef PNP_STAMPS
@@ -89,13 +92,15 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false,
 hipError_t launch_conv3x3_bf16ws(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s);
 size_t conv3x3_partial_floats(const ConvPlan& p, int N, int H, int W, int Cout);
 bool conv3x3_pooled_output_ok(const ConvPlan& p);
+bool conv3x3_tensor_fits(int N, int H, int W, int Cin, int Cout);   // whole-tensor buffer descriptors: < 2 GiB per activation tensor
 hipError_t launch_conv3x3(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s);
 
 // Host-side repack of OIHW conv3x3 weights into the per-lane MFMA B-fragment stream (chunk size ck from the
 // layer's plan).  dst must hold conv3x3_pack_floats(cin, cout) floats.
 size_t conv3x3_pack_floats(int cin, int cout);
 void pack_conv3x3_weights(const float* oihw, int cin, int cout, int ck, float* dst);
-void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, float* dst);   // same buffer size bound
+size_t conv3x3_pack_floats_bf16(int cin, int cout, int terms);
+void pack_conv3x3_weights_bf16(const float* oihw, int cin, int cout, int ck, int terms, float* dst);
 
 // Winograd F(2x2,3x3) path for the K-heavy layers (winograd_kernels.hip).
 struct WinoPlan {

@@ -266,7 +266,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
             const int tr = t / TC;
             const int py = STK ? 4 * (tr % (TR / 2)) : 4 * tr, px = 4 * (t % TC);
             const int gy = ty0 + py, gx = tx0 + px;                            // top-left pixel of the tile
-            // Bounds without per-store compares: W is a multiple of 4, so a 4-wide tile is inside or outside the image as a WHOLE in
+            // Bounds without per-store compares: W is a multiple of 4 (winograd_plan admits no other width: the column step is a
+            // scalar offset the range check does not see), so a 4-wide tile is inside or outside the image as a WHOLE in
             // x (one select per tile); its rows travel in the vector offset, so a row past H is past the descriptor's num_records
             // (one slice) and the store is dropped by the range check; only the column step is a scalar offset.
             const unsigned base = (gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cout + cout0) * 4) : OOB;
@@ -994,7 +995,7 @@ static hipError_t launch_wino4_inst(const ConvArgs& a, const WinoPlan& p, hipStr
 
 // `a.wpack` must be the F(4x4) pack (pack_winograd4_weights).
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a0, const WinoPlan& p, int src_mode, hipStream_t s) {
-    if (!p.use || p.algo != 4 || a0.Cout % p.bn || a0.Cin % p.ck || (src_mode == SRC_UPCAT && a0.Cskip % p.ck)) return hipErrorInvalidValue;
+    if (!p.use || p.algo != 4 || a0.Cout % p.bn || a0.Cin % p.ck || (src_mode == SRC_UPCAT && a0.Cskip % p.ck) || a0.W % 4) return hipErrorInvalidValue;
     if (a0.last_w != nullptr && !(p.bn == 32 && p.mt == 32 && src_mode == SRC_PLAIN)) return hipErrorInvalidValue;   // fused last layer: 32-channel variant
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;

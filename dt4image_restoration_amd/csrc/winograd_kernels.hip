@@ -79,7 +79,8 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
     // 64-channel output blocks, 32 tiles of 4x4 pixels per workgroup (16 x 32 or 32 x 16 pixels), so the image must be at
     // least that large in the tile's long direction - or 16 x 16 exactly, where two slices are stacked into one workgroup.
     if (!t.no_f4 && Cin >= t.f4_min_cin && (Cout % 64 == 0 || Cout == 32) && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
-        W >= 16 && H >= 16 && (W >= 32 || H >= 32 || (W == 16 && H == 16 && src_mode == SRC_PLAIN && N >= 2))) {
+        W >= 16 && H >= 16 && (W >= 32 || H >= 32 || (W == 16 && H == 16 && src_mode == SRC_PLAIN && N >= 2)) &&
+        W % 4 == 0) {   // (its epilogue stores 4-wide tiles whole in x, wino4_epilogue: other widths - 34, 18 - take F(2x2) / direct)
         WinoPlan f{};
         f.algo = 4;
         // tile order: an XCD walks a contiguous range of spatial tiles (halo pixels shared through its L2: -1...2.7 % on the 256 / 128

@@ -417,9 +417,11 @@ class GreedyEvaluator:
             a, b = bounds[k], bounds[k + 1]
             if k not in self._forks:
                 self._forks[k] = self.env if k == 0 else self.env.fork(k)
-                # two streams per sub-batch: its env steps on a normal-priority stream, its policy calls on a HIGH-priority one -
-                # a policy kernel is a few workgroups that must not queue behind the thousands of the other sub-batch's convs
-                self._streams[k] = {"step": torch.cuda.Stream(device=dev), "policy": torch.cuda.Stream(device=dev, priority=-1)}
+                # ONE stream per sub-batch, for its env steps and its policy calls alike: every tensor of the sub-batch is allocated,
+                # written and read on that stream, so the caching allocator can never hand a block back while another stream still
+                # reads it (a separate high-priority stream for the policy calls measured no faster and needed record_stream on
+                # every tensor crossing over)
+                self._streams[k] = torch.cuda.Stream(device=dev)
             def cut(key, v):
                 v = torch.as_tensor(v)
                 if key == "mask":
@@ -427,34 +429,32 @@ class GreedyEvaluator:
                 return v[a:b] if v.dim() > 0 and v.shape[0] == n else v
             sub = {key: cut(key, v) for key, v in mat.items()}
             st = self._streams[k]
-            st["policy"].wait_stream(cur)
+            st.wait_stream(cur)
             out: Dict[str, object] = {}
             gens.append(self._run_phases(sub, rtg[a:b], task[a:b], None, self._forks[k], k, out))
             outs.append(out)
             streams.append(st)
-        # round-robin over the sub-batches, one phase each; sub-batch k starts k phases late so that steps and policy calls of
-        # different sub-batches face each other.  A sub-batch's phases alternate between its two streams; each phase first waits
-        # for the stream of the phase before it (the chain step -> policy -> step is a true dependency).
+        # round-robin over the sub-batches, one phase (a policy call or an env step) each; sub-batch k starts k phases late so that
+        # steps and policy calls of different sub-batches face each other.  Stream order carries the chain step -> policy -> step.
         live = [True] * parts
-        last = ["step"] * parts                             # the phase a sub-batch enqueued last ("step": the next one is a policy phase)
         rnd = 0
         while any(live):
             for k in range(parts):
                 if not live[k] or rnd < k:
                     continue
-                nxt = "policy" if last[k] == "step" else "step"
-                streams[k][nxt].wait_stream(streams[k][last[k]])
-                with torch.cuda.stream(streams[k][nxt]):
+                with torch.cuda.stream(streams[k]):
                     try:
-                        last[k] = next(gens[k])
+                        next(gens[k])
                     except StopIteration:
                         live[k] = False
-                        last[k] = nxt
             rnd += 1
         for k in range(parts):
-            cur.wait_stream(streams[k]["step"])
-            cur.wait_stream(streams[k]["policy"])
+            cur.wait_stream(streams[k])
         res = [o["result"] for o in outs]
+        for r in res:                                       # allocated on a sub-batch's stream, read from here on on the caller's
+            for t in (r.reward, r.initial_reward, r.stop_time, r.actions, r.x):
+                if t.is_cuda:
+                    t.record_stream(cur)
         return GreedyResult(reward=torch.cat([r.reward for r in res]), initial_reward=torch.cat([r.initial_reward for r in res]),
                             stop_time=torch.cat([r.stop_time for r in res]), actions=torch.cat([r.actions for r in res]),
                             x=torch.cat([r.x for r in res]))

@@ -211,6 +211,10 @@ class PnPEngine:
         _lib.check(self.lib.pnp_conv_algorithms(self._h, out), "pnp_conv_algorithms")
         return list(out)
 
+    def bf16_weight_terms(self) -> int:
+        """bf16 terms per conv weight: 0 on an f32 handle, 2 in bf16 mode (hi + lo), 1 with PNP_BF16_W1 (ablation)."""
+        return int(self.lib.pnp_bf16_weight_terms(self._h))
+
     # -- kernel timing ---------------------------------------------------------------------
     def profile_reset(self) -> None:
         _lib.check(self.lib.pnp_profile_reset(self._h), "pnp_profile_reset")

@@ -41,16 +41,55 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def _stage(sd, prefix: str, x: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
+# first conv index (execution order 0..27) of each ConvBlock, for per-layer operand plans
+_STAGE_BASE = {"inc.conv": 0, "down1.mpconv.1": 3, "down2.mpconv.1": 6, "down3.mpconv.1": 9, "down4.mpconv.1": 12,
+               "up1.conv": 15, "up2.conv": 18, "up3.conv": 21, "up4.conv": 24}
+
+
+class Bf16Plan:
+    """Operand rounding of the engine's PNP_FLAG_BF16_CONVS mode, per conv layer (index 0..27 in execution order; only the
+    conv3x3 layers with Cin >= 32 take part).
+
+    acts:          conv inputs are rounded to bfloat16 (nearest even)
+    weight_terms:  2 (the engine's default) - a weight is carried as TWO bfloat16 terms hi = bf16(w), lo = bf16(w - hi): the
+                   matrix pipe multiplies the rounded activations by hi and by lo and accumulates both products in f32, which
+                   is the convolution with the 16-bit-mantissa weight hi + lo (the sum is exact in f32);
+                   1 - one bfloat16 term (PNP_BF16_W1: the round-3 arithmetic, 0.015 dB off the f32 reference after 50
+                   iterations at 512 x 512); 0 - f32 weights (experiments only)
+    layer_terms:   {layer index: terms} overrides (tools/bf16_drift.py)
+    `True` where a plan is expected means Bf16Plan()."""
+
+    def __init__(self, acts: bool = True, weight_terms: int = 2, layer_terms=None):
+        self.acts, self.weight_terms, self.layer_terms = acts, weight_terms, dict(layer_terms or {})
+
+    def operands(self, li: int, x: torch.Tensor, w: torch.Tensor):
+        if self.acts:
+            x = _bf16(x)
+        terms = self.layer_terms.get(li, self.weight_terms)
+        if terms == 2:
+            hi = _bf16(w)
+            w = hi + _bf16(w - hi)
+        elif terms == 1:
+            w = _bf16(w)
+        return x, w
+
+
+def _plan(q):
+    return None if not q else (q if isinstance(q, Bf16Plan) else Bf16Plan())
+
+
+def _stage(sd, prefix: str, x: torch.Tensor, bf16_operands=False) -> torch.Tensor:
     """ConvBlock: 3 x [conv3x3 s1 p1 + bias, LeakyReLU(0.2)]  (evaluation/noise.py:88-98, 75-85).
 
-    bf16_operands (BASELINE configs[4], not the reference's arithmetic): every conv with Cin >= 32 sees its input tensor
-    and its weights rounded to bfloat16; products and sums stay in the working precision, bias is not rounded."""
+    bf16_operands (BASELINE configs[4], not the reference's arithmetic; True or a Bf16Plan): every conv with Cin >= 32 sees
+    its input tensor rounded to bfloat16 and its weights as one or two bfloat16 terms, as the plan says; products and sums
+    stay in the working precision, bias is not rounded."""
+    plan = _plan(bf16_operands)
     for j in range(3):
         w = sd[f"{prefix}.conv-{j}.conv2d.weight"]
         b = sd[f"{prefix}.conv-{j}.conv2d.bias"]
-        if bf16_operands and w.shape[1] >= 32:
-            x, w = _bf16(x), _bf16(w)
+        if plan is not None and w.shape[1] >= 32:
+            x, w = plan.operands(_STAGE_BASE[prefix] + j, x, w)
         x = F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), LEAKY)
     return x
 
@@ -166,7 +205,7 @@ def admm_step(sd: Mapping[str, torch.Tensor], st: "OrderedDict[str, torch.Tensor
 
 
 def run_episode(sd, data, mu_tab: np.ndarray, sig_tab: np.ndarray, iters: int, dtype=torch.float32,
-                record_psnr: bool = True):
+                record_psnr: bool = True, bf16_operands=False):
     """reset + `iters` steps with per-slice parameter tables [N,iters]; returns (state, psnr[N,iters])."""
     st = reset(data, dtype)
     n = st["z"].shape[0]
@@ -174,7 +213,7 @@ def run_episode(sd, data, mu_tab: np.ndarray, sig_tab: np.ndarray, iters: int, d
     sg_t = torch.from_numpy(np.asarray(sig_tab)).to(dtype).reshape(n, -1)
     hist = []
     for t in range(iters):
-        st, _ = admm_step(sd, st, mu_t[:, t], sg_t[:, t], None)
+        st, _ = admm_step(sd, st, mu_t[:, t], sg_t[:, t], None, bf16_operands)
         if record_psnr:
             hist.append(psnr(st["x"], st["gt"])[:, 0])
     return st, (torch.stack(hist, dim=1) if hist else None)

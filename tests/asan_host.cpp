@@ -62,8 +62,12 @@ int main() {
                 const size_t pf = conv3x3_pack_floats(L.cin, L.cout);
                 float* dst = (float*)std::malloc(pf * sizeof(float));
                 pack_conv3x3_weights(w.data(), L.cin, L.cout, cp.ck, dst);
-                pack_conv3x3_weights_bf16(w.data(), L.cin, L.cout, cb.ck, dst);
                 std::free(dst);
+                for (int terms = 1; terms <= 2; ++terms) {                          // bf16 mode: one- and two-term weight packs
+                    float* d16 = (float*)std::malloc(conv3x3_pack_floats_bf16(L.cin, L.cout, terms) * sizeof(float));
+                    pack_conv3x3_weights_bf16(w.data(), L.cin, L.cout, cb.ck, terms, d16);
+                    std::free(d16);
+                }
                 ++packed_layers;
             }
     CHECK(packed_layers > 100);

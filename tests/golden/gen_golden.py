@@ -73,10 +73,41 @@ def ref_state(data, i, dtype=torch.float32):
                         "gt": torch.from_numpy(data["gt"][i:i + 1]).to(dtype), "T": 0})
 
 
+def gen_g8(PnPEnv, torch_psnr, UNetDenoiser2D):
+    """G8: BASELINE configs[4] at its stated length - 512x512, 8x radial mask, 50 iterations (+ the bench's 3 warm-up steps
+    = 53), the parameter table `bench.py --size 512 --accel 8 --steps 50 --warmup 3` steps with (rows 0, 1 of
+    synthetic.param_table(n, 53, seed=77) for any n), 2 independent single-slice runs of the reference's own PnPEnv.step
+    (env.py:74-100) in f32: per-iteration PSNR [2,53] and the final image of slice 0."""
+    n8, it8 = 2, 53
+    sd0 = weights.generate_unet_weights(0, "unit_gain")
+    data8 = synthetic.make_problem(n8, 512, 512, accel=8.0, sigma_n=10.0 / 255.0, seed=1234)
+    mu_tab, sig_tab = synthetic.param_table(n8, it8, seed=77)
+    env = PnPEnv.__new__(PnPEnv)
+    env.denoiser = ref_denoiser(UNetDenoiser2D, sd0)
+    ps = np.zeros((n8, it8))
+    xfin = None
+    for i in range(n8):
+        st = ref_state(data8, i)
+        with torch.no_grad():
+            for t in range(it8):
+                act = OrderedDict(T=torch.tensor(0.0), mu=torch.tensor(float(mu_tab[i, t])),
+                                  sigma_d=torch.tensor([float(sig_tab[i, t])]))
+                st, _ = env.step(st, act)
+                ps[i, t] = float(torch_psnr(st["x"].reshape(1, 512, 512), st["gt"].reshape(1, 512, 512)))
+        if i == 0:
+            xfin = st["x"].numpy()[0, 0].astype(np.float32)
+        print("G8 slice", i, ps[i, ::13], flush=True)
+    np.savez_compressed(os.path.join(HERE, "g8_config4.npz"), psnr=ps, x_final_slice0=xfin, mu_tab=mu_tab, sig_tab=sig_tab,
+                        size=np.array(512), accel=np.array(8.0))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     PnPEnv, torch_psnr, UNet, UNetDenoiser2D, fft, ifft = import_reference()
+    if "--only-g8" in sys.argv:
+        gen_g8(PnPEnv, torch_psnr, UNetDenoiser2D)
+        return
     out = {}
 
     # ---- G1: centred FFT pair ------------------------------------------------------
@@ -127,7 +158,7 @@ def main():
                                            for a in acts.values()])
     np.savez_compressed(os.path.join(HERE, "g2_unet.npz"), **g2)
 
-    # ---- G3 / G8: config-1 trajectory (128x128, 10 iters, mu=0.1, sigma_d=15/255) -----
+    # ---- G3: config-1 trajectory (128x128, 10 iters, mu=0.1, sigma_d=15/255), f32 and the f64 sensitivity record -----
     sd0 = weights.generate_unet_weights(0, "unit_gain")
     data = synthetic.make_problem(1, 128, 128, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
     g3 = {}
@@ -192,6 +223,9 @@ def main():
             g6[f"x_{t}"] = np.array(st["x"].real.numpy())
             g6[f"T_{t}"] = np.array(float(st["T"]))
     np.savez_compressed(os.path.join(HERE, "g6_earlystop.npz"), **g6)
+
+    # ---- G8: configs[4] at its stated length (512x512, 8x mask, 53 iterations) ---------------
+    gen_g8(PnPEnv, torch_psnr, UNetDenoiser2D)
     print("golden vectors written to", HERE)
 
 

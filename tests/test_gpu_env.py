@@ -459,3 +459,74 @@ def test_stopped_slice_in_a_stacked_workgroup_is_untouched(denoiser):
         assert torch.equal(a1[k][1], b1[k][1])                       # the stopped slice
         for i in (0, 2, 3):
             assert torch.equal(a1[k][i], a0[k][i]), (k, i)           # its workgroup mate (slice 0) and the others
+
+
+# ---- round 4: BASELINE configs[4] at its stated length -----------------------------------------------------------------------
+def _g8_episode(engine, g, n=2):
+    """Step the fixture's 53 iterations on `engine`; returns PSNR [n,53] and the final x."""
+    data = synthetic.make_problem(n, 512, 512, accel=8.0, sigma_n=10.0 / 255.0, seed=1234)
+    gt = torch.from_numpy(data["gt"]).cuda()
+    x, z, u = engine.reset(torch.view_as_complex(torch.from_numpy(data["x0"])).cuda(),
+                           torch.view_as_complex(torch.from_numpy(data["y0"])).cuda(), torch.from_numpy(data["mask"]).cuda())
+    mu = torch.from_numpy(g["mu_tab"][:n].copy()).cuda()
+    sg = torch.from_numpy(g["sig_tab"][:n].copy()).cuda()
+    hist = []
+    for t in range(g["psnr"].shape[1]):
+        engine.step(x, z, u, mu[:, t].contiguous(), sg[:, t].contiguous())
+        hist.append(engine.psnr(x, gt))
+    return torch.stack(hist, dim=1).cpu().numpy(), x.cpu().numpy()
+
+
+def test_config4_f32_53_iterations_match_reference(denoiser, golden_dir):
+    """512x512, 8x radial mask, bench.py's parameter table, ALL 53 iterations (50 timed + 3 warm-up of `bench.py --size 512
+    --accel 8 --steps 50 --warmup 3`) against what the reference's own PnPEnv.step produced slice by slice (g8_config4.npz):
+    the first reference-pinned 512x512 trajectory."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    g = np.load(os.path.join(golden_dir, "g8_config4.npz"))
+    e = PnPEngine(2, 512, 512)
+    e.load_weights(denoiser.weights)
+    ps, xf = _g8_episode(e, g)
+    d = np.abs(ps - g["psnr"])
+    assert d.max() < PSNR_TOL_DB, d.max(axis=0)
+    assert d.max() < 1e-3                                   # (measured ~1e-5: f32 summation order only)
+    # FLOAT TOLERANCE: 53 iterations of the f32 U-Net (Winograd tiling vs ATen's direct sum) + FFTs
+    np.testing.assert_allclose(xf[0, 0], g["x_final_slice0"], rtol=0, atol=1e-4)
+
+
+def test_config4_bf16_53_iterations_within_tolerance_of_reference(denoiser, golden_dir):
+    """BASELINE configs[4] AS STATED AND AT ITS STATED LENGTH: 512x512, 8x undersampling, bf16 denoiser convs, 50 iterations
+    (+ bench.py's 3 warm-up steps).  north_star's +-0.01 dB against the REFERENCE's f32 trajectory (g8_config4.npz) at every one of
+    the 53 iterations.  Weights ride as two bf16 terms (hi + lo): with one term the offset passes 0.01 dB near iteration 45
+    (the one-term arithmetic is kept behind PNP_BF16_W1 and measured in the next test)."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    g = np.load(os.path.join(golden_dir, "g8_config4.npz"))
+    e = PnPEngine(2, 512, 512, bf16_convs=True)
+    e.load_weights(denoiser.weights)
+    ps, _ = _g8_episode(e, g)
+    d = np.abs(ps - g["psnr"])
+    print("bf16 (two-term weights) |dPSNR| vs reference at it 1, 10, 30, 50, 53:", d[:, [0, 9, 29, 49, 52]].max(axis=0), "max", d.max())
+    assert d.max() < PSNR_TOL_DB, d.max(axis=0)
+    assert d.max() < 0.005                                  # oracle (tools/bf16_drift.py): 0.002-0.003 with two-term weights
+
+
+def test_config4_bf16_one_term_weights_drift_is_what_the_oracle_says(denoiser, golden_dir, monkeypatch):
+    """PNP_BF16_W1 (ablation): one bf16 term per weight, the round-3 arithmetic.  The engine follows the oracle's one-term mode
+    (first iterations, same rounding points) and its offset to the reference after 53 iterations is the drift the two-term
+    weights remove (0.015 dB in the oracle; asserted only to exceed the two-term bound, the sign of the per-layer contributions is
+    seed-dependent)."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    from oracle import pnp_oracle as O
+    g = np.load(os.path.join(golden_dir, "g8_config4.npz"))
+    monkeypatch.setenv("PNP_BF16_W1", "1")
+    e = PnPEngine(2, 512, 512, bf16_convs=True)
+    monkeypatch.delenv("PNP_BF16_W1")
+    e.load_weights(denoiser.weights)
+    ps, _ = _g8_episode(e, g)
+    d = np.abs(ps - g["psnr"])
+    print("bf16 (one-term weights) |dPSNR| vs reference at it 1, 10, 30, 50, 53:", d[:, [0, 9, 29, 49, 52]].max(axis=0), "max", d.max())
+    assert d.max() < 0.03
+    data = synthetic.make_problem(2, 512, 512, accel=8.0, sigma_n=10.0 / 255.0, seed=1234)
+    sd = O.torch_weights(denoiser.weights)
+    with torch.no_grad():
+        _, ho = O.run_episode(sd, data, g["mu_tab"], g["sig_tab"], 2, bf16_operands=O.Bf16Plan(weight_terms=1))
+    assert np.abs(ps[:, :2] - ho.numpy()).max() < 2e-3      # the engine's one-term mode IS the oracle's one-term mode

@@ -183,7 +183,8 @@ def test_winograd_path_matches_oracle_per_stage(sd_np, n, h, w, monkeypatch):
 
 @pytest.mark.parametrize("n,h,w,min_cin", [(2, 128, 128, 128), (2, 96, 112, 128), (1, 144, 64, 128), (1, 256, 256, 128), (3, 128, 64, 64),
                                            (3, 256, 256, 64),       # 16 x 16 bottom level: two slices stacked per workgroup (odd batch)
-                                           (2, 128, 128, 32), (1, 80, 48, 32)])   # + the Cout = 32 / Cin = 32 layers (4-wave variant)
+                                           (2, 128, 128, 32), (1, 80, 48, 32),    # + the Cout = 32 / Cin = 32 layers (4-wave variant)
+                                           (8, 272, 272, 32), (2, 256, 144, 32)])  # level widths 34 / 18, 9: not multiples of 4 - F(2x2) / direct there
 @pytest.mark.parametrize("schedule", ["default", "in-step", "independent"])
 def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, schedule, monkeypatch):
     """F(4x4,3x3) (winograd4_kernels.hip, points 0, +-3/4, +-3/2, inf) on every layer it can take - workgroup gate lifted so
@@ -201,6 +202,9 @@ def test_winograd_f4_path_matches_oracle_per_stage(sd_np, n, h, w, min_cin, sche
     e = _engine(n, h, w, sd_np, keep_stages=True)
     algos = e.conv_algorithms()
     assert sum(1 for v in algos if v == 4) >= (9 if min_cin <= 64 and min(h, w) >= 128 else 1), algos
+    # the F(4x4) epilogue stores 4-wide tiles whole in x: a level whose width is no multiple of 4 must not be planned on it
+    from dt4image_restoration_amd import unet_spec
+    assert all(algos[l.index] != 4 for l in unet_spec.UNET_LAYERS[1:27] if (w >> l.level) % 4 != 0), algos
     sd = O.torch_weights(sd_np)
     x = (torch.from_numpy(synthetic.hash_uniform(19, h * 100 + w, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5
     sigma = torch.linspace(5, 50, n) / 255.0

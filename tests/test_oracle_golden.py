@@ -96,3 +96,35 @@ def test_g6_early_stop(golden_dir):
         np.testing.assert_allclose(x.numpy(), g[f"x_{t}"], rtol=0, atol=2e-6)
         assert abs(float(st["T"][0]) - float(g[f"T_{t}"])) < 1e-6
     np.testing.assert_array_equal(g["x_2"], g["x_1"])     # the stopped step changed nothing
+
+
+def test_g8_config4_trajectory_prefix_and_bf16_plan(golden_dir):
+    """BASELINE configs[4] (512x512, 8x radial mask, bench.py's parameter table): the f32 oracle against the reference's own
+    per-iteration PSNR (g8_config4.npz) over the first iterations of slice 0 - the full 53 iterations are stepped by the GPU
+    tests against the same fixture; the CPU suite stays within minutes -, and the fixture's inputs are the ones bench.py
+    generates for any batch size (rows 0, 1 of the table do not depend on n)."""
+    g = _load(golden_dir, "g8_config4.npz")
+    assert g["psnr"].shape == (2, 53) and int(g["size"]) == 512 and float(g["accel"]) == 8.0
+    mu16, sg16 = synthetic.param_table(16, 53, seed=77)
+    np.testing.assert_array_equal(mu16[:2], g["mu_tab"])
+    np.testing.assert_array_equal(sg16[:2], g["sig_tab"])
+    data = synthetic.make_problem(1, 512, 512, accel=8.0, sigma_n=10.0 / 255.0, seed=1234)
+    sd = O.torch_weights(weights.generate_unet_weights(0, "unit_gain"))
+    iters = 8
+    with torch.no_grad():
+        _, hist = O.run_episode(sd, data, g["mu_tab"][:1], g["sig_tab"][:1], iters)
+    # FLOAT TOLERANCE: same ATen ops as the reference, batched over one slice; thread-count dependent summation order only
+    np.testing.assert_allclose(hist[0].numpy(), g["psnr"][0, :iters], rtol=0, atol=1e-4)
+
+
+def test_bf16_plan_two_terms_carry_sixteen_mantissa_bits():
+    """Bf16Plan: hi + lo reproduces a weight to 2^-16 relative (one term: 2^-8, half an ulp of the 8-bit significand), and the
+    sum is exact in f32."""
+    w = torch.from_numpy(synthetic.hash_uniform(3, 5, 4096).astype(np.float32)) * 0.3
+    x = torch.ones(1)
+    for terms, bound in ((1, 2.0 ** -8), (2, 2.0 ** -16)):
+        _, wq = O.Bf16Plan(weight_terms=terms).operands(1, x, w)
+        assert float(((wq - w).abs() / w.abs().clamp_min(1e-30)).max()) <= bound
+    hi = O._bf16(w)
+    lo = O._bf16(w - hi)
+    assert torch.equal((hi.double() + lo.double()).float(), hi + lo)
