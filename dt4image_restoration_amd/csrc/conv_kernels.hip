@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     constexpr int KS = 9 * (CK / KCH); // k-steps per chunk
     // B fragments in flight (k-steps ahead).  PFD must divide KS (18 or 36 / 9 or 18) so that a chunk's k-step j always sits
     // in slot j % PFD; a bf16 k-step is only MT*NT*32 cycles of MFMA, so the small tiles look 9 k-steps ahead.
+    // (two-term weights, small tiles: a ring of 6 k-steps would do for the latency and spill less, but measured NONDETERMINISTIC
+    // results on the split-K variants - profiles/r04_ablation.md - and is not used)
     constexpr int PFD = BF16 ? (MT * NT <= 2 ? 9 : 3) : 2;
     static_assert(KS % PFD == 0, "slot rotation must line up at chunk boundaries");
     constexpr int PPP = CK / 4;        // 16-byte pieces per pixel
@@ -558,7 +560,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     } else {
         // Two full 128-B lines per store instruction; per-slot address part in the scalar offset of a buffer store,
-        // per-lane part in one VGPR per N-block.  Split-K workgroups store raw partial sums to plane blockIdx.z.
+        // per-lane part in one VGPR per N-block.  Split-K workgroups store raw partial sums to plane blockIdx.z
+        // (combined by splitk_reduce_kernel; an in-launch combine by the last-arriving workgroup - device-scope fences around an arrival
+        // counter - was built and measured in round 4: 0.90 against 0.546 ms per step at 1 x 128 x 128, the L2 write-back / invalidate
+        // of every workgroup's fence costs more than the 21 launches it saves; profiles/r04_ablation.md).
         const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
         float* const obuf = SPLITK ? a.partial + (size_t)blockIdx.z * plane : a.dst;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obuf, 0, (int)(plane * sizeof(float)), 0x00020000);

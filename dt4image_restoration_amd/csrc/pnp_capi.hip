@@ -403,6 +403,11 @@ int pnp_create(const pnp_config* cfg, pnp_handle* out) {
         return fail(PNP_ERR_INVALID, "pnp_create: need n >= 1 and h, w multiples of 16 (got n=%d h=%d w=%d)", cfg->n,
                     cfg->h, cfg->w);
     if (cfg->h > 1024 || cfg->w > 1024) return fail(PNP_ERR_INVALID, "pnp_create: h, w <= 1024");
+    // the conv kernels' x2 upsample reads two compile-time source lines per output row (commit_lo / interpolate): holds in float32
+    // for every even height up to 1024 - checked, not assumed
+    for (int k = 0; k < 4; ++k)
+        if (!(cfg->flags & PNP_FLAG_NO_DENOISER) && !upsample_lines_regular(cfg->h >> k))
+            return fail(PNP_ERR_INVALID, "pnp_create: upsample to %d rows is not line-regular in float32", cfg->h >> k);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)

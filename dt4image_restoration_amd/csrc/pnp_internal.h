@@ -114,6 +114,7 @@ struct WinoPlan {
 };
 // `src_mode` = the source mode the layer will be LAUNCHED with (a POOL layer whose producer writes the pooled copy runs PLAIN)
 WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, const Tuning& t);
+bool upsample_lines_regular(int H);   // winograd4_kernels.hip: the x2 upsample to H rows reads lines floor((g - 1) / 2), + 1 in float32 too
 size_t winograd4_pack_floats(int cin, int cout);
 void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float* dst);
 hipError_t launch_conv3x3_winograd4(const ConvArgs& a, const WinoPlan& p, int src_mode, hipStream_t s);

@@ -157,6 +157,26 @@ void pack_winograd4_weights(const float* oihw, int cin, int cout, int ck, float*
     }
 }
 
+// The F(4x4) kernels' interpolation assumes that output row g of an exact x2 bilinear upsample (align_corners=True) to H rows reads
+// the source lines floor((g - 1) / 2) and the next one (clamped), with a non-zero weight on no other line - true in exact arithmetic;
+// here it is checked against the float32 product rh * g that ATen (and these kernels' weight tables) evaluate.  True for every even
+// H up to 1024 (tools: python check in DESIGN.md); winograd_plan plans an upsample + concat layer on F(4x4) only where it holds.
+bool upsample_lines_regular(int H) {
+    if (H < 2 || H % 2) return false;
+    const int Hs = H / 2;
+    const float rh = (float)(Hs - 1) / (float)(H - 1);
+    for (int g = 0; g < H; ++g) {
+        const float sc = rh * (float)g;
+        const int i0 = (int)sc;
+        const int i1 = i0 + (i0 < Hs - 1 ? 1 : 0);
+        const float l = sc - (float)i0;
+        const int s0 = g >= 1 ? (g - 1) / 2 : -1;
+        if (l < 1.f && i0 != s0 && i0 != s0 + 1) return false;       // weight 1 - l on line i0
+        if (l > 0.f && i1 != s0 && i1 != s0 + 1) return false;       // weight l on line i1
+    }
+    return true;
+}
+
 // ---- blockIdx -> (channel block, spatial tile).  Blocks b and b + 8 share an XCD under round-robin placement (speed only, never
 // correctness).  Both orders run the channel blocks of one spatial tile back to back on ONE XCD, so the patch they all read comes
 // into that L2 once.  order 0 (rounds 1-2): XCD k takes the spatial tiles k, k + 8, k + 16, ... - a tile's neighbours sit on other
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     constexpr int NIT = (ITEMS + NT_ - 1) / NT_;
     constexpr bool UP2 = SRC == SRC_UPCAT;
     constexpr bool FIRST = SRC == SRC_FIRST;           // the patch is the denoiser's FIRST layer, computed here (see first_patch)
-    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region bound (rows, cols)
+    constexpr int LH = TH / 2 + 3, LW = TW / 2 + 3;    // low-res region (rows, cols): rows [ty0 / 2 - 1, ...) - see interpolate() -, cols from xlo
     constexpr int LITEMS = LH * LW * PPP;
     constexpr int NITL = (LITEMS + NT_ - 1) / NT_;
     // SPLIT (64-channel upsample + concat variants): a skip chunk's NIT staging loads go out in TWO half-batches - the first at the
@@ -371,8 +391,8 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     float* const patch = smem;                             // [PH][PW][CKQ]
     float* const V = smem + ((PH * PW * CKQ + 3) & ~3);    // [36][MT tiles][CKP]
     float* const lowres = V + 36 * PLANE;                  // UPCAT: [LH][LW][LP] low-res source region of the chunk being staged
-    float* const rowT = lowres + LH * LW * LP;             // UPCAT: per patch row / column {offset of the two source lines in the
-    float* const colT = rowT + 4 * PH;                     // low-res region (int), their two weights}; zeros outside the image
+    float* const rowT = lowres + LH * LW * LP;             // UPCAT: per patch row the weights of its three candidate source lines; per patch
+    float* const colT = rowT + 4 * PH;                     // column {offsets of its two source columns in the region (int), their weights}
     // FIRST: image halo tile (2 pixels around the patch... 1 around each patch pixel's 3x3 window), its in-image mask, and the
     // first layer's weights [18 taps][32 channels] (sigma taps pre-scaled by sigma), bias, and the sigma taps' per-channel sum
     constexpr int IW = PW + 3;                             // row stride of the image tile (PW + 2 used)
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     const int nchunks = a.Cin / CK;
 
     const int Hs = a.H >> 1, Ws = a.W >> 1;
-    const int ylo = UP2 ? (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)) : 0;
+    const int ylo = UP2 ? ty0 / 2 - 1 : 0;                 // first low-res row of the parked region (-1 at the top of the image: a zero row)
     const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
     const int nskip = UP2 ? a.Cskip / CK : 0;              // leading chunks that come straight from the skip tensor
 
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             const int idx = tid + k * NT_;
             const int part = idx % PPP, pp = idx / PPP;
             const int sy = ylo + pp / LW, sx = xlo + pp % LW;
-            voffL[k] = (idx < LITEMS && sy < Hs && sx < Ws) ? (unsigned)(((sy * Ws + sx) * Cup + part * 4) * 4) : OOB;
+            voffL[k] = (idx < LITEMS && sy >= 0 && sy < Hs && sx < Ws) ? (unsigned)(((sy * Ws + sx) * Cup + part * 4) * 4) : OOB;
         }
     }
     const int ldst = ((tid / PPP) * CKQ + (tid % PPP) * 4);      // patch slot of item 0; item k is k * (NT_ / PPP) pixels further
@@ -505,23 +525,52 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         }
     };
     // upsampled chunk: interpolate the patch from the parked low-res region (ATen upsample_bilinear2d, align_corners=True:
-    // src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46)
+    // src = dst * (in-1)/(out-1), weights (1-l, l), noise.py:39,46): out = wy0 (wx0 p[i0][c0] + wx1 p[i0][c1]) + wy1 (... p[i1] ...).
+    // SEPARABLE (round 4): a lane owns one (patch column, 4-channel piece) and the rows of its row group.  It first forms
+    // t[k] = wx0 p[k][c0] + wx1 p[k][c1] for the low-res lines its rows touch - every read at a compile-time offset from one
+    // address, all in flight together - and then each patch row as a weighted sum of two of them: for an exact x2 upsample the
+    // source lines of output row g >= 1 are floor((g - 1) / 2) and the next (winograd_plan checks that the float product
+    // rh * g ATen evaluates agrees for every row of this image height - it does for every even height up to 1024), so patch row y
+    // of a tile whose first row is even touches lines s, s + 1 with s = ty0 / 2 - 1 + (y >> 1): two compile-time registers; the
+    // per-row table holds their weights, filled from the float formula.  Same products and sums per output value as
+    // interpolating each piece from its four source pixels, ~7 packed vector instructions per output piece instead of 27 and
+    // three LDS round trips per chunk instead of two per piece (the f32 MFMAs share the vector issue port: interpolation was
+    // 0.20-0.25 of these kernels' lifetime, profiles/r03_wino4_stamps.md).  PW x PPP lanes of IWPG waves work per row group, ING
+    // groups split the rows.
+    constexpr int IPAIRS = PW * PPP, IWPG = (IPAIRS + 63) / 64, ING = (NT_ / 64) / IWPG;
+    constexpr int IRG = (((PH + ING - 1) / ING) + 1) & ~1;                // rows per group, even: (y >> 1) splits into group and row part
+    constexpr int IK = IRG / 2 + 1;                                        // low-res lines a row group touches
+    static_assert(!UP2 || (ING >= 1 && (PPP & (PPP - 1)) == 0 && TH % 2 == 0), "row groups of whole waves; even tile origin");
+    static_assert(!UP2 || ((PH - 1) / 2 + 1 < LH), "the parked region holds every candidate line");
     auto interpolate = [&]() {
-#pragma unroll                                             // three items' reads in flight together (the staging registers are free
-        for (int k = 0; k < NIT; ++k) {                    // here): one item at a time is a chain of LDS round trips
-            if (k % (MT == 16 ? 2 : 3) == 0) __builtin_amdgcn_sched_barrier(0);
-            const int idx = tid + k * NT_;
-            const int part = idx % PPP, pp = idx / PPP;
-            const int py = pp / PW, px = pp % PW;
-            if (idx < ITEMS) {
-                const float4 rt = *reinterpret_cast<const float4*>(&rowT[4 * py]), ct = *reinterpret_cast<const float4*>(&colT[4 * px]);
-                const float* l0 = &lowres[__float_as_int(rt.x) + part * 4];
-                const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
-                const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
-                put_patch(pp * CKQ + part * 4,
-                          f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
-                                  *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
-                                  ct.z, ct.w, rt.z, rt.w));
+        const int ig = wid / IWPG;                         // this wave's row group (wave-uniform)
+        const int it = tid - ig * (IWPG * 64);
+        if (ig >= ING || it >= IPAIRS) return;
+        const int x = it / PPP, part = it % PPP;
+        const int yb = ig * IRG;
+        const float4 ct = *reinterpret_cast<const float4*>(&colT[4 * x]);
+        const float* const l0 = &lowres[__float_as_int(ct.x) + part * 4 + (yb / 2) * (LW * LP)];
+        const float* const l1 = &lowres[__float_as_int(ct.y) + part * 4 + (yb / 2) * (LW * LP)];
+        const v2f wx0 = v2f{ct.z, ct.z}, wx1 = v2f{ct.w, ct.w};
+        v2f tl[IK], th_[IK];
+#pragma unroll
+        for (int k = 0; k < IK; ++k) {                     // wx0 * p[line][c0] + wx1 * p[line][c1], 4 channels
+            if ((yb / 2 + k) < LH) {                       // (wave-uniform; lines past the region belong to rows past the patch)
+                const float4 pa = *reinterpret_cast<const float4*>(l0 + k * (LW * LP)), pb = *reinterpret_cast<const float4*>(l1 + k * (LW * LP));
+                tl[k] = __builtin_elementwise_fma(wx0, v2f{pa.x, pa.y}, wx1 * v2f{pb.x, pb.y});
+                th_[k] = __builtin_elementwise_fma(wx0, v2f{pa.z, pa.w}, wx1 * v2f{pb.z, pb.w});
+            } else { tl[k] = v2f{0.f, 0.f}; th_[k] = v2f{0.f, 0.f}; }
+        }
+        const int pdst = ((yb * PW + x) * CKQ) + part * 4;
+#pragma unroll
+        for (int j = 0; j < IRG; ++j) {
+            if (yb + j < PH) {                             // (wave-uniform)
+                const float4 rw = *reinterpret_cast<const float4*>(&rowT[4 * (yb + j)]);
+                const v2f wa = v2f{rw.x, rw.x}, wb = v2f{rw.y, rw.y};
+                const int k = j >> 1;
+                const v2f olo = __builtin_elementwise_fma(wa, tl[k], wb * tl[k + 1]);
+                const v2f ohi = __builtin_elementwise_fma(wa, th_[k], wb * th_[k + 1]);
+                put_patch(pdst + j * (PW * CKQ), make_float4(olo.x, olo.y, ohi.x, ohi.y));
             }
         }
     };
@@ -602,6 +651,8 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     if constexpr (UP2) {
         // the interpolation's coordinates are the same for every chunk: one table entry per patch row and column, built once
         // (first read behind the loop-top barrier).  Pixels outside the image (the conv's zero padding) get zero weights.
+        // Row entry: the weights of the row's two candidate source lines s, s + 1 (see interpolate()); column entry:
+        // {offsets of the two source columns in the region, their weights}.
         if (tid < PH + PW) {
             const bool isrow = tid < PH;
             const int pq = isrow ? tid : tid - PH;
@@ -612,8 +663,16 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
                 const int i0 = (int)sc;
                 const int i1 = i0 + (i0 < (isrow ? Hs : Ws) - 1 ? 1 : 0);
                 const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
-                const int lo = isrow ? ylo : xlo, mul = isrow ? LW * LP : LP;
-                e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+                if (isrow) {
+                    const int s0 = ylo + (pq >> 1);        // the row's first candidate line
+                    const float w0 = 1.f - l, w1 = l;
+                    e.x = (i0 == s0 ? w0 : 0.f) + (i1 == s0 ? w1 : 0.f);
+                    e.y = (i0 == s0 + 1 ? w0 : 0.f) + (i1 == s0 + 1 ? w1 : 0.f);
+                    // (a line outside the two candidates can only carry the weight l = 0 of image row 0, where sc = 0:
+                    // upsample_lines_regular(), checked by winograd_plan)
+                } else {
+                    e = make_float4(__int_as_float((i0 - xlo) * LP), __int_as_float((i1 - xlo) * LP), 1.f - l, l);
+                }
             }
             *reinterpret_cast<float4*>(&(isrow ? rowT : colT)[4 * pq]) = e;
         }

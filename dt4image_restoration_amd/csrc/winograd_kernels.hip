@@ -80,7 +80,8 @@ WinoPlan winograd_plan(int N, int H, int W, int Cin, int Cout, int src_mode, con
     // least that large in the tile's long direction - or 16 x 16 exactly, where two slices are stacked into one workgroup.
     if (!t.no_f4 && Cin >= t.f4_min_cin && (Cout % 64 == 0 || Cout == 32) && Cin % 16 == 0 && (src_mode == SRC_PLAIN || src_mode == SRC_UPCAT) &&
         W >= 16 && H >= 16 && (W >= 32 || H >= 32 || (W == 16 && H == 16 && src_mode == SRC_PLAIN && N >= 2)) &&
-        W % 4 == 0) {   // (its epilogue stores 4-wide tiles whole in x, wino4_epilogue: other widths - 34, 18 - take F(2x2) / direct)
+        W % 4 == 0 &&   // (its epilogue stores 4-wide tiles whole in x, wino4_epilogue: other widths - 34, 18 - take F(2x2) / direct)
+        (src_mode != SRC_UPCAT || upsample_lines_regular(H))) {   // (its interpolation: two compile-time source lines per patch row)
         WinoPlan f{};
         f.algo = 4;
         // tile order: an XCD walks a contiguous range of spatial tiles (halo pixels shared through its L2: -1...2.7 % on the 256 / 128

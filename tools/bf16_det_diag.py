@@ -1,0 +1,30 @@
+"""GPU box diagnostic: which U-Net stage is the first to differ between two identical denoiser passes (bf16 mode)?"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dt4image_restoration_amd.engine import PnPEngine
+from dt4image_restoration_amd.weights import generate_unet_weights
+from dt4image_restoration_amd import synthetic
+
+n, h, w = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+sdn = generate_unet_weights(0, "unit_gain")
+e = PnPEngine(n, h, w, bf16_convs=True, keep_stages=True); e.load_weights(sdn)
+print("algos", e.conv_algorithms()[1:27], "terms", e.bf16_weight_terms())
+x = ((torch.from_numpy(synthetic.hash_uniform(9, 64256, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
+sigma = (torch.linspace(3, 60, n) / 255.0).cuda()
+ref = None
+for rep in range(4):
+    e.denoise(x, sigma)
+    st = [e.read_stage(k).clone() for k in range(9)]
+    if ref is None:
+        ref = st
+    else:
+        print("rep", rep, "stage diffs:", [int((a != b).sum()) for a, b in zip(st, ref)])
+    if rep == 1:
+        d = (st[5] != ref[5])            # [n, C, h, w] of the first upsample stage
+        if int(d.sum()) > 0:
+            nn, cc, yy, xx = torch.nonzero(d, as_tuple=True)
+            print(" y % 8 histogram", torch.bincount(yy % 8, minlength=8).tolist())
+            print(" x % 32 histogram", torch.bincount(xx % 32, minlength=32).tolist())
+            print(" channel % 32 histogram", torch.bincount(cc % 32, minlength=32).tolist())
+            print(" channel // 32 histogram", torch.bincount(cc // 32, minlength=8).tolist())
+            print(" slices affected", len(torch.unique(nn)), "max abs", float((st[5] - ref[5]).abs().max()), "ref max", float(ref[5].abs().max()))
