@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     // in slot j % PFD; a bf16 k-step is only MT*NT*32 cycles of MFMA, so the small tiles look 9 k-steps ahead.
     // (two-term weights, small tiles: a ring of 6 k-steps would do for the latency and spill less, but measured NONDETERMINISTIC
     // results on the split-K variants - profiles/r04_ablation.md - and is not used)
-    constexpr int PFD = BF16 ? (MT * NT <= 2 ? 9 : 3) : 2;
+    // (two-term weights: a slot holds two fragments and a k-step is twice as long - 6 slots cover the latency 9 did and the
+    // three-workgroups-per-CU variants stop spilling)
+    constexpr int PFD = BF16 ? (MT * NT <= 2 ? (NW == 2 ? 6 : 9) : 3) : 2;
     static_assert(KS % PFD == 0, "slot rotation must line up at chunk boundaries");
     constexpr int PPP = CK / 4;        // 16-byte pieces per pixel
     constexpr int BM = WM * MT * 32;   // pixels per workgroup tile

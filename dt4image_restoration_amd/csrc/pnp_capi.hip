@@ -189,6 +189,9 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
             a.first_w = e->d_wpack[0]; a.first_b = e->d_bias[0]; a.first_sigma = sigma;
             a.last_ximg = ximg; a.last_z = z; a.last_u = u;
         }
+#ifdef PNP_DIAG
+        if (const char* dv = getenv("PNP_DIAG_L0")) a.diag = L.level == 0 ? atoi(dv) : 0;
+#endif
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;
         if (e->wino[li] && e->wplan[li].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[li], src_mode, s));
@@ -228,6 +231,9 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         a.act16 = e->abits[26] & 1;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
         a.last_w = e->d_wpack[27]; a.last_b = e->d_bias[27]; a.last_ximg = ximg; a.last_z = z; a.last_u = u; a.last_out = out;
+#ifdef PNP_DIAG
+        if (const char* dv = getenv("PNP_DIAG_L0")) a.diag = atoi(dv);
+#endif
         {
             Prof p(e, s, 0, 26, per_layer);
             ++run_launches;

@@ -74,6 +74,12 @@ struct ConvArgs {
 #ifdef PNP_STAMPS
     int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
 #endif
+#ifdef PNP_DIAG
+    int diag;            // diagnostic build (`make diag`, timing only, results wrong): bit 0 = the F(4x4) epilogue's global stores are dropped
+                         // (descriptor of zero records: same instruction stream), bit 1 = every workgroup stages the patch of tile 0 of
+                         // slice 0 (L2 hits instead of HBM reads).  Set per launch from PNP_DIAG_L0 for the level-0 layers: the compute-only
+                         // time of a layer = what a fused conv-1 -> conv-2 pair could at best pay per layer (profiles/r04_level0_bound.md)
+#endif
 };
 
 // Launch the conv3x3 (+bias +LeakyReLU 0.2) implicit-GEMM kernel matching `a` (picks the tile shape

@@ -237,12 +237,17 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
     };
     if (!live) return;                                     // stacked: wave th works on slice n + th, which may have stopped
     const bool fused = FUSE && a.last_w != nullptr;        // (uniform over the workgroup)
+#ifdef PNP_DIAG
+    const bool nostore = (a.diag & 1) != 0;
+#else
+    constexpr bool nostore = false;
+#endif
     v2f part[2];                                           // fused: pixel cl of tiles 4 tg + (0,1), (2,3), summed over this wave's channels
     const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, a.H * a.W * a.Cout * 4, 0x00020000);
+        (void*)(a.dst + (size_t)(n + (STK ? th : 0)) * a.H * a.W * a.Cout), 0, nostore ? 0 : a.H * a.W * a.Cout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.pooled != nullptr ? a.pooled + (size_t)(n + (STK ? th : 0)) * Hp * Wp * a.Cout : a.dst), 0,
-        a.pooled != nullptr ? Hp * Wp * a.Cout * 4 : 0, 0x00020000);
+        (a.pooled != nullptr && !nostore) ? Hp * Wp * a.Cout * 4 : 0, 0x00020000);
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
         v2f T[4][6];
@@ -329,7 +334,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 for (int r = 0; r < 4; ++r) {
                     const int t = 16 * th + 4 * tg + r;
                     const int gy = ty0 + 4 * (t / TC) + (cl >> 2), gx = tx0 + 4 * (t % TC) + (cl & 3);
-                    if (gy < a.H && gx < a.W) {
+                    if (gy < a.H && gx < a.W && !nostore) {
                         const size_t qx = ((size_t)n * a.H + gy) * a.W + gx;
                         const float img = a.last_ximg != nullptr ? a.last_ximg[qx] : (a.last_z[qx].x - a.last_u[qx].x);
                         a.last_out[qx] = fminf(fmaxf(img + sum[r] + lb, 0.f), 1.f);
@@ -442,8 +447,14 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
     // transform.)
     constexpr unsigned OOB = 0x80000000u;
     const int cs = UP2 ? a.Cskip : a.Cin;
+#ifdef PNP_DIAG
+    const bool hot = (a.diag & 2) != 0;                    // timing only: every workgroup stages tile 0 of slice 0
+#else
+    constexpr bool hot = false;
+#endif
+    const int ly0 = hot ? 0 : ty0, lx0 = hot ? 0 : tx0, ln = hot ? 0 : n;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.src0 + (size_t)n * a.H * a.W * cs), 0, nsl * a.H * a.W * cs * 4, 0x00020000);
+        (void*)(a.src0 + (size_t)ln * a.H * a.W * cs), 0, nsl * a.H * a.W * cs * 4, 0x00020000);
     unsigned voff[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -451,20 +462,20 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
         const int part = idx % PPP, pp = idx / PPP;
         const int py = pp / PW, px = pp % PW;
         const int sub = STK ? py / SUBH : 0;                               // stacked: which of the two slices
-        const int gy = STK ? py % SUBH - 1 : ty0 + py - 1, gx = tx0 + px - 1;
+        const int gy = STK ? py % SUBH - 1 : ly0 + py - 1, gx = lx0 + px - 1;
         voff[k] = (idx < ITEMS && sub < nsl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                       ? (unsigned)((((sub * a.H + gy) * a.W + gx) * cs + part * 4) * 4) : OOB;
     }
     const int Cup = a.Cin - a.Cskip;
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(UP2 ? a.src1 + (size_t)n * Hs * Ws * Cup : a.src0), 0, UP2 ? Hs * Ws * Cup * 4 : 0, 0x00020000);
+        (void*)(UP2 ? a.src1 + (size_t)ln * Hs * Ws * Cup : a.src0), 0, UP2 ? Hs * Ws * Cup * 4 : 0, 0x00020000);
     unsigned voffL[UP2 ? NITL : 1];
     if constexpr (UP2) {
 #pragma unroll
         for (int k = 0; k < NITL; ++k) {
             const int idx = tid + k * NT_;
             const int part = idx % PPP, pp = idx / PPP;
-            const int sy = ylo + pp / LW, sx = xlo + pp % LW;
+            const int sy = (hot ? -1 : ylo) + pp / LW, sx = (hot ? 0 : xlo) + pp % LW;
             voffL[k] = (idx < LITEMS && sy >= 0 && sy < Hs && sx < Ws) ? (unsigned)(((sy * Ws + sx) * Cup + part * 4) * 4) : OOB;
         }
     }
