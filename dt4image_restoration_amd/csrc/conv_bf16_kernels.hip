@@ -487,6 +487,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             }
         }
 
+        WS_STAMP(0);                                           // (diagnostic build: end of the tile's k-loops)
         if (t_next < total) {                                  // the next tile's bias and first weight fragments
             const int wn0 = wbase(t_next);
 #pragma unroll
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            WS_STAMP(0);                                       // (diagnostic build: output tile written to LDS)
             const int wy0 = ty0 + wid * (WPX / TW);            // the wave's first image row
             if (a.last_w != nullptr) {
                 const int gy = wy0 + lane / TW, gx = tx0 + lane % TW;          // one pixel per lane
