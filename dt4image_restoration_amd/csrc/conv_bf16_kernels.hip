@@ -398,7 +398,6 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
     const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * sizeof(float)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc16 = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(plane * 2), 0x00020000);
     // What a tile needs from memory besides its patches is requested ahead, so that a tile boundary costs the consumers no
     // round trip: the next live tile (a tact[] read) at the start of this one, its bias values and the first PFD k-steps
     // of its weights right after this tile's last k-loop - they land under the epilogue's stores.  (The ring's refills of a
@@ -581,29 +580,47 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         // epilogue: LeakyReLU(0.2), NHWC store; per-slot address part in the scalar offset of a buffer store, per-lane part in
         // one VGPR per N-block
         if (a.act16 & 2) {
-            // bf16 dst: lanes (2j, 2j+1) hold channels (2j, 2j+1) of the same pixels; they swap one value per pixel PAIR
-            // (DPP quad_perm [1,0,3,2]) so that the even lane stores pixel r's channel pair and the odd lane pixel r+1's:
-            // 4 B per lane, 64 B contiguous per pixel, half the store instructions of the f32 form
+            // bf16 dst.  Lanes (2j, 2j+1) hold channels (2j, 2j+1) of the same pixels; they swap one value per pixel PAIR (DPP quad_perm
+            // [1,0,3,2]) so that the even lane holds pixel r's channel pair and the odd lane pixel r+1's (4 B each).  Round 4: the pairs
+            // go through LDS - one M-block (32 pixels x NT x 32 channels) at a time into THIS WAVE's slice of the patch buffer the tile's
+            // last k-loop just read (free until the barrier that follows: the producers are committing into the other buffer) - and
+            // leave as 16-byte stores over whole 64 / 128-byte channel runs: 4 x MT store instructions per lane, every one full lines,
+            // instead of 8 x MT x NT four-byte stores on 64-byte fragments, which took a third of a level-1 tile (~10000 cycles,
+            // `profiles/r04_bf16ws_stamps.txt`) and held up the next tile's first weight fragments behind them.
+            constexpr int SSTR = NT * 16 + 4;                  // staged pixel: NT * 64 bytes of channels + 16 bytes of skew, in floats
+            constexpr int CPP = NT * 4;                        // 16-byte pieces per staged pixel
+            static_assert(4 * 32 * SSTR <= PATCH && (32 * CPP) % 64 == 0, "four wave slices fit one patch buffer; whole rounds of 64 lanes");
+            unsigned* const st = reinterpret_cast<unsigned*>(patch + ((g - 1) & 1) * PATCH) + wid * (32 * SSTR);
             const bool odd = (li & 1) != 0;
+            uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
+            const int cw0 = (cbt * (WN * NT) + wn * NT) * 32;  // this wave's first output channel
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + (li & ~1);
-                const unsigned obase = ((unsigned)(((size_t)n * a.H + ty0) * a.W + tx0 + 4 * hh + (odd ? 1 : 0)) * (unsigned)a.Cout + (unsigned)co) * 2u;
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+                for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // pixel of register r (r + 1: the next pixel in the row)
-                        const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh + (odd ? 1 : 0);
-                        const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 2);
+                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * hh + (odd ? 1 : 0);   // pixel of the M-block this lane's pair belongs to
                         const float x = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
                         const float y = fmaxf(acc[mt][nt][r + 1], kLeaky * acc[mt][nt][r + 1]);
                         const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? x : y), 0xB1, 0xf, 0xf, false));
                         const bf16x2 pk = __builtin_convertvector((f32x2){odd ? got : x, odd ? y : got}, bf16x2);   // round to nearest even
-                        if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), orsrc16, obase, soff, 0);
+                        st[pl * SSTR + nt * 16 + (li >> 1)] = __builtin_bit_cast(unsigned, pk);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 32 * CPP / 64; ++i) {
+                    const int f = lane + 64 * i, pl = f / CPP, c8 = f % CPP;
+                    const int q = (wm * MT + mt) * 32 + pl;
+                    const int gy = ty0 + q / TW, gx = tx0 + q % TW;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&st[pl * SSTR + c8 * 4]);
+                    if (gy < a.H && gx < a.W)
+                        *reinterpret_cast<uint4*>(d16 + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cw0 + 8 * c8) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);             // (the next M-block's LDS writes follow these reads in program order)
             }
         } else {
 #pragma unroll
