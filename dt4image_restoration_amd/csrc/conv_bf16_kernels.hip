@@ -21,6 +21,7 @@
 // so the producers are already fetching the next tile while the consumers store this one.
 #include "pnp_internal.h"
 #include "conv_staging.h"
+#include <cstdlib>
 // Diagnostic build (-DPNP_WS_STAMPS, `make stamps`; tools/ws_stamps.py): s_memtime of consumer wave 0 and producer wave 4 of one
 // workgroup at every hand-over, per launch.
 #ifdef PNP_WS_STAMPS
@@ -59,8 +60,14 @@ constexpr int bf16ws_lds_floats() {
 // NW: bf16 terms per weight.  2 (the mode's default): every k-step multiplies its A fragments by the weight's hi AND lo term
 // (pack_conv3x3_weights_bf16: hi = bf16(w), lo = bf16(w - hi), 1 KiB each per k-step and N-block, hi first), 2 x MT x NT MFMAs into
 // the same accumulators - the convolution with the 16-bit-mantissa weight hi + lo.  1: PNP_BF16_W1, the round-3 arithmetic.
-template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW>
+// HOLDHI (32 -> 32 layers on the 2 x 1 tile under two-term weights: one chunk, one output-channel block - every tile multiplies by the SAME
+// 18 k-steps of weights): a consumer wave keeps BOTH fragments of all 18 k-steps in registers (144) for the life of the workgroup and
+// streams no weights at all.  The four consumer waves of that tile fetched identical fragments, two per 128 MFMA cycles each = 64 B/clk per
+// CU, which is what the L1 delivers: the tile's k-loop ran at 0.67 of the matrix rate (`profiles/r04_bf16ws_stamps.txt`).  hi held: -10 % on
+// inc.conv-1 / inc.conv-2 / up4.conv-1, both held: -18 % (`profiles/r04_ablation.md`; PNP_BF16_NO_HOLDHI switches it off).
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW, bool HOLDHI = false>
 __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
+    static_assert(!HOLDHI || (NT == 1 && NW == 2 && SRC == SRC_PLAIN), "held hi fragments: the 32 -> 32 tile");
     constexpr int CK = 32;
     constexpr int KS = 9 * (CK / 16);   // k-steps (16 channels) per chunk
     constexpr int KB = NW * 1024;       // bytes of one k-step of one N-block in the weight stream
@@ -423,6 +430,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) bq[p][nt][w] = wload(wbase(t) + nt * wstride + p * KB + w * 1024);
     }
+    float4 bhi[HOLDHI ? KS : 1], blo[HOLDHI ? KS : 1];                            // HOLDHI: both fragments of every k-step (Cin = 32: one chunk)
+    if constexpr (HOLDHI) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { bhi[ks] = wload(ks * KB); blo[ks] = wload(ks * KB + 1024); }
+    }
     int g = 0;
     WS_STAMP(0);
     while (t < total) {
@@ -471,13 +483,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]),
-                                                                                  __builtin_bit_cast(bf16x8, bq[ks % PFD][nt][w]), acc[mt][nt], 0, 0, 0);
+                                                                                  __builtin_bit_cast(bf16x8, HOLDHI ? (w == 0 ? bhi[HOLDHI ? ks : 0] : blo[HOLDHI ? ks : 0]) : bq[ks % PFD][nt][w]), acc[mt][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // refill the slot just read with k-step ks + PFD of the stream (this chunk's, or the following chunk's first ones)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int w = 0; w < NW; ++w)
+                    for (int w = HOLDHI ? NW : 0; w < NW; ++w)
                         bq[ks % PFD][nt][w] = wload((ks + PFD < KS ? wc + (ks + PFD) * KB : wfollow + (ks + PFD - KS) * KB) + nt * wstride + w * 1024);
                 if (ks + 1 < KS) {
 #pragma unroll
@@ -646,18 +658,23 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
 }
 
-template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW>
+template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW, bool HOLDHI = false>
 static hipError_t launch_k(const ConvArgs& a, unsigned grid, hipStream_t s) {
     constexpr int BYTES = bf16ws_lds_floats<TW, WM, MT, NT, SRC>() * 4;
     static DeviceOnce once;
-    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW>), BYTES, once);
+    const hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW, HOLDHI>), BYTES, once);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW>), dim3(grid), dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_bf16ws_kernel<TW, WM, WN, MT, NT, SRC, A16S, NW, HOLDHI>), dim3(grid), dim3(512), BYTES, s, a);
     return hipGetLastError();
 }
 
 template <int TW, int WM, int WN, int MT, int NT, int SRC>
 static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
+    if constexpr (NT == 1 && SRC == SRC_PLAIN) {           // 32 -> 32 layers: the hi fragments stay in registers (HOLDHI)
+        static const bool off = getenv("PNP_BF16_NO_HOLDHI") != nullptr;   // (ablation switch, process-wide)
+        if (a.bf16 == 2 && a.Cin == 32 && a.Cout == 32 && !off)
+            return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 2, true>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 2, true>(a, grid, s);
+    }
     if (a.bf16 == 2)
         return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 2>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 2>(a, grid, s);
     return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 1>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 1>(a, grid, s);
