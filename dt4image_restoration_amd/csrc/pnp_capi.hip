@@ -191,6 +191,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         }
 #ifdef PNP_DIAG
         if (const char* dv = getenv("PNP_DIAG_L0")) a.diag = L.level == 0 ? atoi(dv) : 0;
+        if (const char* dv = getenv("PNP_DIAG_ALL")) a.diag = atoi(dv);
 #endif
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;

@@ -798,6 +798,9 @@ __global__ __launch_bounds__(8 * MT * WN, 2) void conv3x3_wino4_kernel(const Con
             }
             // refill the slot just read: this chunk's fragment xi + PF, or one of the next chunk's first KEEP (the stream is
             // contiguous across chunks; tail zero-padded)
+#ifdef PNP_DIAG
+            if ((a.diag & 4) && (xi & 1)) continue;        // timing only: every second weight fragment is not fetched (stale one reused)
+#endif
             if (xi + PF < 36 + KEEP) bq[xi % PF] = bfrag(bp, bf0, xi + PF);
         }
 #ifdef PNP_STAMPS
@@ -1002,6 +1005,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4p_kernel(const ConvArgs a
             acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[xi], 0, 0, 0);
             acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[xi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef PNP_DIAG
+            if ((a.diag & 4) && (xi & 1)) continue;        // timing only: every second weight fragment is not fetched (stale one reused)
+#endif
             if (xi + PF < 36 + KEEP) bq[xi % PF] = bp[(xi + PF) * 64];
         }
 #ifdef PNP_STAMPS
