@@ -40,12 +40,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS floats of a workgroup: two patches of (TH+2) x (TW+2) pixels x 80 B; UPCAT adds the f32 low-res source region of one
 // upsampled chunk ((TH/2+3) x (TW/2+3) pixels x 36 floats) and two copies (tile parity) of the interpolation table.
-// The 32-channel tile (NT = 1) adds its epilogue's transpose space, 36 floats per tile pixel.
+// The 32-channel tile (NT = 1) adds its epilogue's transpose space, 36 floats per tile pixel; the others the staging space of their
+// bf16 epilogue, one M-block (32 pixels x NT * 64 + 16 bytes) per consumer wave.
 template <int TW, int WM, int MT, int NT, int SRC>
 constexpr int bf16ws_lds_floats() {
     constexpr int TH = WM * MT * 32 / TW, PH = TH + 2, PW = TW + 2;
     return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0) +
-           (NT == 1 ? WM * MT * 32 * 36 : 0) + 256;         // + the stopped-tile flags
+           (NT == 1 ? WM * MT * 32 * 36 : 4 * 32 * (NT * 16 + 4)) + 256;         // + the stopped-tile flags
 }
 
 // A16S: src0 (the PLAIN / POOL source, the UPCAT skip tensor) holds bf16 - written so by the launch that produced it, rounded
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float patch[];   // bf16ws_lds_floats(): 54-130 KB, dynamic
     float* const lowres = patch + 2 * PATCH;                        // UPCAT: [LH * LW][CKL]
     float* const tabs = lowres + (UP2 ? LH * LW * CKL : 0);         // UPCAT: [2][PH + PW] x {offset of source line 0, 1; weight 0, 1}
-    float* const epi = tabs + (UP2 ? 2 * 4 * (PH + PW) : 0);        // NT = 1: [BM][36] output tile, a wave's rows private to it
+    float* const epi = tabs + (UP2 ? 2 * 4 * (PH + PW) : 0);        // NT = 1: [BM][36] output tile, a wave's rows private to it;
+                                                                    // else [4 consumer waves][32][NT * 16 + 4] bf16-pair staging
     const int nskip = UP2 ? a.Cskip / CK : 0;
 
     const int tid = threadIdx.x;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     // ... - are fetched once into LDS: a read of tact[] per tile is a memory round trip in both roles' critical paths, and
     // a 32-channel tile is only ~2 us of work.
     constexpr int MAXLIVE = 256;
-    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? BM * 36 : 0));
+    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? BM * 36 : 4 * 32 * (NT * 16 + 4)));
     const int mine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
     const bool cached = a.tact != nullptr && mine <= MAXLIVE;
     if (cached) {
@@ -594,15 +596,18 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         if (a.act16 & 2) {
             // bf16 dst.  Lanes (2j, 2j+1) hold channels (2j, 2j+1) of the same pixels; they swap one value per pixel PAIR (DPP quad_perm
             // [1,0,3,2]) so that the even lane holds pixel r's channel pair and the odd lane pixel r+1's (4 B each).  Round 4: the pairs
-            // go through LDS - one M-block (32 pixels x NT x 32 channels) at a time into THIS WAVE's slice of the patch buffer the tile's
-            // last k-loop just read (free until the barrier that follows: the producers are committing into the other buffer) - and
-            // leave as 16-byte stores over whole 64 / 128-byte channel runs: 4 x MT store instructions per lane, every one full lines,
+            // go through LDS - one M-block (32 pixels x NT x 32 channels) at a time into THIS WAVE's staging slice - and leave as
+            // 16-byte stores over whole 64 / 128-byte channel runs: 4 x MT store instructions per lane, every one full lines,
             // instead of 8 x MT x NT four-byte stores on 64-byte fragments, which took a third of a level-1 tile (~10000 cycles,
             // `profiles/r04_bf16ws_stamps.txt`) and held up the next tile's first weight fragments behind them.
+            // (The slices are LDS of their own.  The first form of this epilogue staged in the patch buffer the tile's last k-loop
+            // had just read - free of the PRODUCERS until the next barrier, but not of the other consumer waves, which read the same
+            // patch and are not in step: a wave one M-block's conversion ahead overwrote A fragments a slower one had yet to
+            // read.  It passed every parity test; the repeatability test caught it once, late in the round.)
             constexpr int SSTR = NT * 16 + 4;                  // staged pixel: NT * 64 bytes of channels + 16 bytes of skew, in floats
             constexpr int CPP = NT * 4;                        // 16-byte pieces per staged pixel
-            static_assert(4 * 32 * SSTR <= PATCH && (32 * CPP) % 64 == 0, "four wave slices fit one patch buffer; whole rounds of 64 lanes");
-            unsigned* const st = reinterpret_cast<unsigned*>(patch + ((g - 1) & 1) * PATCH) + wid * (32 * SSTR);
+            static_assert((32 * CPP) % 64 == 0, "whole rounds of 64 lanes");
+            unsigned* const st = reinterpret_cast<unsigned*>(epi) + wid * (32 * SSTR);
             const bool odd = (li & 1) != 0;
             uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
             const int cw0 = (cbt * (WN * NT) + wn * NT) * 32;  // this wave's first output channel

@@ -67,8 +67,17 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src
     // Small problems (the reference's own batch-1 128x128 case): the big tiles leave most CUs idle behind a serial
     // K loop.  Use narrow tiles and cut K into `splitk` ranges of whole chunks, one workgroup each; the partial sums
     // are combined in a fixed order by splitk_reduce_kernel (bit-reproducible, unlike float atomics).
+    // Round 4: what bounds such a launch is ONE WAVE's chain of MFMAs - a 32-channel chunk on a 2 x 1 register tile is 288
+    // v_mfma_f32_32x32x2_f32 = 7.7 us - on a chip with most SIMDs idle, so the f32 plan cuts finer: one 32-pixel M-block per
+    // wave and 16-channel chunks (72 MFMAs per chunk, twice the tiles, twice the K ranges): 20 -> 14 us per layer at
+    // 1 x 128 x 128 (profiles/r04_ablation.md).  (bf16 k-steps are sixteen times shorter; that mode keeps the round-3 tiles.)
+    // The upsample + concat layers keep the round-3 tile (their chain is the two-stage staging, not the MFMAs: no gain measured), and
+    // 384 workgroups stays the target (256: -10 % at 5 x 256 x 256).
+    static const bool coarse = getenv("PNP_SPLITK_COARSE") != nullptr;       // (A/B: the round-3 tiles)
+    const bool fine = !coarse && !bf16;
     if (blocks < 128 && Cout >= 64) {
-        p.mt = 2; p.nt = 1; p.ck = 32;
+        const bool f = fine && src_mode != SRC_UPCAT;
+        p.mt = f ? 1 : 2; p.nt = 1; p.ck = f ? 16 : 32;
         if (Cout % 128 == 0) { p.wm = 1; p.wn = 4; } else { p.wm = 2; p.wn = 2; }
         blocks = finish();
         const int nchunks = Cin / p.ck;
@@ -76,6 +85,9 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src
         if (sk > nchunks) sk = nchunks;
         while (nchunks % sk != 0) --sk;             // equal ranges
         p.splitk = sk;
+    } else if (blocks <= 128 && Cout == 32 && fine) {
+        p.mt = 1;                                   // 128-pixel tiles (LDS epilogue, pooled copy and fused last layer as on the 256-pixel tile)
+        blocks = finish();
     }
     // bf16 mode, chip-filling problems: the producer / consumer kernel (conv_bf16_kernels.hip) takes the layers with
     // Cout >= 64 (sources PLAIN, UPCAT; POOL on the 256 x 128 tile), 512-pixel x 64-channel tiles for Cout = 64,
@@ -189,8 +201,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     constexpr int KS = 9 * (CK / KCH); // k-steps per chunk
     // B fragments in flight (k-steps ahead).  PFD must divide KS (18 or 36 / 9 or 18) so that a chunk's k-step j always sits
     // in slot j % PFD; a bf16 k-step is only MT*NT*32 cycles of MFMA, so the small tiles look 9 k-steps ahead.
-    // (two-term weights, small tiles: a ring of 6 k-steps would do for the latency and spill less, but measured NONDETERMINISTIC
-    // results on the split-K variants - profiles/r04_ablation.md - and is not used)
     // (two-term weights: a slot holds two fragments and a k-step is twice as long - 6 slots cover the latency 9 did and the
     // three-workgroups-per-CU variants stop spilling)
     constexpr int PFD = BF16 ? (MT * NT <= 2 ? (NW == 2 ? 6 : 9) : 3) : 2;
@@ -499,12 +509,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         __syncthreads();
         constexpr int V4 = BN / 4;
         const int cbase = cbt * BN;
-        if constexpr (BN == 32 && BM == 256) {
+        if constexpr (BN == 32 && BM <= 256) {
             if (a.last_w != nullptr) {
                 // Fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1, + image channel, clamp; this conv's own
                 // 32-channel output is never written.  One pixel per thread.
                 const int gy = ty0 + tid / TW, gx = tx0 + tid % TW;
-                if (gy < a.H && gx < a.W) {
+                if (tid < BM && gy < a.H && gx < a.W) {
                     float dsum = a.last_b[0];
 #pragma unroll
                     for (int c4 = 0; c4 < 8; ++c4) {
@@ -562,13 +572,17 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
         }
     } else {
         // Two full 128-B lines per store instruction; per-slot address part in the scalar offset of a buffer store,
-        // per-lane part in one VGPR per N-block.  Split-K workgroups store raw partial sums to plane blockIdx.z
-        // (combined by splitk_reduce_kernel; an in-launch combine by the last-arriving workgroup - device-scope fences around an arrival
-        // counter - was built and measured in round 4: 0.90 against 0.546 ms per step at 1 x 128 x 128, the L2 write-back / invalidate
-        // of every workgroup's fence costs more than the 21 launches it saves; profiles/r04_ablation.md).
+        // per-lane part in one VGPR per N-block.  Split-K workgroups store raw partial sums to plane blockIdx.z, combined either by
+        // splitk_reduce_kernel or (a.arrive != nullptr) in this launch by the LAST of the tile's gridDim.z workgroups to arrive.
+        // The hand-over uses no fence: a device-scope fence (`__threadfence()` = L2 write-back + invalidate of the workgroup's XCD)
+        // per workgroup cost more than the 21 launches it saved (round 4: 0.90 against 0.546 ms per step at 1 x 128 x 128,
+        // profiles/r04_ablation.md).  Instead every access to the shared data is itself agent-scope (sc1: stores write through the
+        // XCD's L2, loads do not hit in it): partial sums stored sc1 - vmcnt(0) - workgroup barrier - one relaxed agent-scope
+        // fetch_add on the tile's arrival counter - the last arrival loads all planes sc1, in plane order (bit-identical to the kernel).
         const size_t plane = (size_t)a.N * a.H * a.W * a.Cout;
         float* const obuf = SPLITK ? a.partial + (size_t)blockIdx.z * plane : a.dst;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obuf, 0, (int)(plane * sizeof(float)), 0x00020000);
+        const bool inlaunch = SPLITK && a.arrive != nullptr;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
@@ -581,8 +595,68 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
                     const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
                     const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
                     const float v = SPLITK ? acc[mt][nt][r] : fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
-                    if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                    if (gy < a.H && gx < a.W) {
+                        if (inlaunch) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 16);   // sc1
+                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
+                    }
                 }
+        }
+        if constexpr (SPLITK) {
+            if (!inlaunch) return;
+            __shared__ unsigned arrived;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial sums have been written through
+            __syncthreads();
+            unsigned* const cnt = a.arrive + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (tid == 0) arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (arrived + 1 != gridDim.z) return;           // (uniform)
+            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            const __amdgpu_buffer_rsrc_t prsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, (int)(plane * gridDim.z * sizeof(float)), 0x00020000);
+            constexpr int V4 = BN_ / 4;
+            const int cbase = cbt * BN_;
+            // four tile positions x four planes in flight per thread: sixteen independent 16-byte loads per round trip (one load
+            // at a time, 8 x gridDim.z dependent round trips of ~0.25 us, this combine cost 2 us per plane)
+            const unsigned nz = gridDim.z, pstride = (unsigned)plane * 4u;
+#pragma unroll 1
+            for (int f0 = tid; f0 < BM * V4; f0 += 4 * 256) {
+                unsigned e[4];
+                bool ok[4];
+                float4 sum[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = f0 + 256 * j, p = f / V4, c4 = f % V4;
+                    const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+                    ok[j] = f < BM * V4 && gy < a.H && gx < a.W;
+                    e[j] = ok[j] ? (unsigned)(((size_t)n * a.H + gy) * a.W + gx) * (unsigned)a.Cout + (unsigned)(cbase + 4 * c4) : 0u;
+                    sum[j] = *reinterpret_cast<const float4*>(a.bias + cbase + 4 * c4);
+                }
+#pragma unroll 1
+                for (unsigned z0 = 0; z0 < nz; z0 += 4) {
+                    float4 q[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned z = z0 + k < nz ? z0 + k : nz - 1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            q[k][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, e[j] * 4u, (int)(z * pstride), 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (z0 + k < nz) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { sum[j].x += q[k][j].x; sum[j].y += q[k][j].y; sum[j].z += q[k][j].z; sum[j].w += q[k][j].w; }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!ok[j]) continue;
+                    float4 v = sum[j];
+                    v.x = fmaxf(v.x, kLeaky * v.x); v.y = fmaxf(v.y, kLeaky * v.y);
+                    v.z = fmaxf(v.z, kLeaky * v.z); v.w = fmaxf(v.w, kLeaky * v.w);
+                    *reinterpret_cast<float4*>(a.dst + e[j]) = v;
+                }
+            }
         }
     }
 }
@@ -594,9 +668,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane4; i += (size_t)gridDim.x * 256) {
         if (tact != nullptr && tact[i / slice4] > 0.5f) continue;
         float4 s = reinterpret_cast<const float4*>(bias)[i % cout4];
-        for (int z = 0; z < splitk; ++z) {
-            const float4 p = reinterpret_cast<const float4*>(partial)[(size_t)z * plane4 + i];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        for (int z0 = 0; z0 < splitk; z0 += 8) {          // eight planes in flight, added in plane order
+            float4 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = reinterpret_cast<const float4*>(partial)[(size_t)(z0 + k < splitk ? z0 + k : splitk - 1) * plane4 + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (z0 + k < splitk) { s.x += p[k].x; s.y += p[k].y; s.z += p[k].z; s.w += p[k].w; }
         }
         s.x = fmaxf(s.x, kLeaky * s.x); s.y = fmaxf(s.y, kLeaky * s.y);
         s.z = fmaxf(s.z, kLeaky * s.z); s.w = fmaxf(s.w, kLeaky * s.w);
@@ -635,8 +713,15 @@ static hipError_t launch_cfg(const ConvArgs& a, const ConvPlan& p, int src_mode,
 
 template <int TW, int BF16>
 static hipError_t launch_tw(const ConvArgs& a, const ConvPlan& p, int src_mode, hipStream_t s) {
+    if constexpr (BF16 == 0) {
+        if (p.mt == 1 && p.wn == 4) return launch_cfg<TW, 1, 1, 1, 4, 16, true, 0>(a, p, src_mode, s);
+        if (p.mt == 1 && p.wn == 2) return launch_cfg<TW, 1, 1, 2, 2, 16, true, 0>(a, p, src_mode, s);
+    }
     if (p.mt == 2 && p.wn == 4) return launch_cfg<TW, 2, 1, 1, 4, 32, true, BF16>(a, p, src_mode, s);    // small problems
     if (p.mt == 2 && p.wn == 2) return launch_cfg<TW, 2, 1, 2, 2, 32, true, BF16>(a, p, src_mode, s);
+    if constexpr (BF16 == 0) {
+        if (p.nt == 1 && p.mt == 1) return launch_cfg<TW, 1, 1, 4, 1, 32, false, 0>(a, p, src_mode, s);      // small problems, Cout = 32
+    }
     if (p.nt == 1) return launch_cfg<TW, 2, 1, 4, 1, 32, false, BF16>(a, p, src_mode, s);
     if (p.nt == 2 && p.wn == 1) return launch_cfg<TW, 4, 2, 4, 1, 16, false, BF16>(a, p, src_mode, s);
     if (p.nt == 2) return launch_cfg<TW, 4, 2, 2, 2, 32, false, BF16>(a, p, src_mode, s);
@@ -651,8 +736,9 @@ hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, h
     ConvArgs a = a0;
     a.tilesX = p.tiles_x;
     a.tilesY = p.tiles_y;
-    const bool split = p.mt == 2 && p.wn >= 2;           // the small-problem configs always go through the workspace
+    const bool split = p.mt <= 2 && p.wn >= 2;          // the small-problem configs always go through the workspace
     if (split && a.partial == nullptr) return hipErrorInvalidValue;
+    if (!split || (size_t)p.tiles_x * p.tiles_y * a.N * (a.Cout / p.bn) > 4096) a.arrive = nullptr;   // (the counters the engine allocates)
     hipError_t e;
     if (a.bf16 == 2) {                                    // bf16 operands, two-term weights (the mode's default)
         if (p.tw == 32) e = launch_tw<32, 2>(a, p, src_mode, s);
@@ -667,7 +753,7 @@ hipError_t launch_conv3x3(const ConvArgs& a0, const ConvPlan& p, int src_mode, h
         else if (p.tw == 16) e = launch_tw<16, 0>(a, p, src_mode, s);
         else e = launch_tw<8, 0>(a, p, src_mode, s);
     }
-    if (e != hipSuccess || !split) return e;
+    if (e != hipSuccess || !split || a.arrive != nullptr) return e;
     const size_t plane4 = (size_t)a.N * a.H * a.W * a.Cout / 4;
     unsigned blocks = (unsigned)((plane4 + 255) / 256);
     if (blocks > 2048u) blocks = 2048u;
@@ -686,11 +772,11 @@ bool conv3x3_tensor_fits(int N, int H, int W, int Cin, int Cout) {
 
 // The direct kernel writes the pooled copy only from its LDS epilogue (Cout = 32 plan on a large problem).
 bool conv3x3_pooled_output_ok(const ConvPlan& p) {   // also: can fuse the last layer
-    return p.splitk == 1 && p.mt == 2 && p.nt == 1 && p.wm == 4;
+    return p.splitk == 1 && p.mt <= 2 && p.nt == 1 && p.wm == 4;
 }
 
 size_t conv3x3_partial_floats(const ConvPlan& p, int N, int H, int W, int Cout) {
-    return (p.mt == 2 && p.wn >= 2) ? (size_t)p.splitk * N * H * W * Cout : 0;
+    return (p.mt <= 2 && p.wn >= 2) ? (size_t)p.splitk * N * H * W * Cout : 0;
 }
 
 Tuning tuning_from_env() {
@@ -710,6 +796,7 @@ Tuning tuning_from_env() {
     t.bf16_f32_acts = getenv("PNP_BF16_F32_ACTS") != nullptr;
     t.bf16_no_ws = getenv("PNP_BF16_NO_WS") != nullptr;
     t.bf16_w1 = getenv("PNP_BF16_W1") != nullptr;
+    if (const char* v = getenv("PNP_SPLITK_INLAUNCH")) t.splitk_inlaunch = atoi(v);
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;
 }

@@ -84,6 +84,7 @@ struct pnp_engine {
     float* d_bias[N_LAYERS] = {};
     LevelBufs lv[5] = {};
     float* d_partial = nullptr;      // split-K workspace (small problems)
+    unsigned* d_arrive = nullptr;    // split-K arrival counters (PNP_SPLITK_INLAUNCH), zero between launches
     Tuning tune;                      // environment overrides, read once in pnp_create
     WinoPlan wplan[N_LAYERS] = {};    // per-layer launch plans, fixed at pnp_create: the weight pack and every launch use
     ConvPlan cplan[N_LAYERS] = {};    // the same plan
@@ -174,7 +175,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         const LayerSpec& L = kLayers[li];
         ConvArgs a{};
         a.pooled = pooled;
-        a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.tact = tact;
+        a.src0 = src0; a.src1 = src1; a.wpack = e->d_wpack[li]; a.bias = e->d_bias[li]; a.dst = dst; a.partial = e->d_partial; a.arrive = e->d_arrive; a.tact = tact;
         a.bf16 = e->bf16_terms;
         a.act16 = e->abits[li];
         a.N = N; a.H = H >> lvl; a.W = W >> lvl; a.Cin = L.cin; a.Cskip = L.cskip; a.Cout = L.cout;
@@ -227,7 +228,7 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         // up4.conv-2 with the last layer (1x1 + residual + clamp) fused into its epilogue: writes `out` directly
         const LayerSpec& L = kLayers[26];
         ConvArgs a{};
-        a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial;
+        a.src0 = e->lv[0].q; a.wpack = e->d_wpack[26]; a.bias = e->d_bias[26]; a.dst = e->lv[0].p; a.partial = e->d_partial; a.arrive = e->d_arrive;
         a.bf16 = e->bf16_terms;
         a.act16 = e->abits[26] & 1;
         a.tact = tact; a.N = N; a.H = H; a.W = W; a.Cin = L.cin; a.Cskip = 0; a.Cout = L.cout;
@@ -348,6 +349,10 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
         if (pf > 0) {
             if (hipMalloc((void**)&e->d_partial, pf * sizeof(float)) != hipSuccess) return fail(PNP_ERR_NOMEM, "split-K workspace");
             e->ws_bytes += pf * sizeof(float);
+            if (e->tune.splitk_inlaunch) {                 // one counter per output tile of a split-K launch: never more than 4096 tiles
+                if (hipMalloc((void**)&e->d_arrive, 4096 * sizeof(unsigned)) != hipSuccess ||
+                    hipMemset(e->d_arrive, 0, 4096 * sizeof(unsigned)) != hipSuccess) return fail(PNP_ERR_NOMEM, "split-K counters");
+            }
         }
         // which stage outputs get a pooled copy: the producing conv (layers 2, 5, 8, 11) must run a kernel whose epilogue
         // goes through LDS - the Winograd kernel, or the direct kernel's Cout = 32 configuration on a large problem
@@ -442,7 +447,7 @@ int pnp_destroy(pnp_handle e) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
     for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); (void)hipFree(L.pool); }
-    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial);
+    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial); (void)hipFree(e->d_arrive);
     (void)hipFree(e->plan.tw_h); (void)hipFree(e->plan.tw_w);
     for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete e;

@@ -28,6 +28,8 @@ struct Tuning {
     bool bf16_w1 = false;         // PNP_BF16_W1 (ablation): bf16 mode with ONE bf16 term per weight (the round-3 arithmetic: 0.015 dB of
                                   // PSNR drift against the f32 reference over configs[4]'s 50 iterations) instead of hi + lo
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
+    int splitk_inlaunch = 0;      // PNP_SPLITK_INLAUNCH (experiments): 1 = split-K planes combined inside the conv launch (agent-scope accesses,
+                                  // no fence) instead of by splitk_reduce_kernel
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
                                   // needs a chip-filling batch to beat the three-launch path: 64.1 vs 78.8 us at 256 slices, 48.9 vs 34.9 at 64)
@@ -62,6 +64,8 @@ struct ConvArgs {
     // from last_ximg or Re(last_z - last_u)): raw [32][18] weights, [32] bias, [N] sigma
     const float* first_w; const float* first_b; const float* first_sigma;
     float* partial;      // split-K workspace, conv3x3_partial_floats() floats (small problems only)
+    unsigned* arrive;    // split-K: per (tile, channel block) arrival counters, zero between launches - the planes are combined in
+                         // the conv launch by the last workgroup to arrive; nullptr: by splitk_reduce_kernel
     const float* tact;   // [N] stop actions or nullptr; slice skipped when tact[n] > 0.5
     int N, H, W;         // OUTPUT spatial size
     int Cin, Cskip, Cout;

@@ -391,7 +391,8 @@ def test_fused_first_and_last_layer_match_their_own_kernels(sd_np, monkeypatch):
 def test_denoiser_passes_are_bit_repeatable(sd_np, mode, monkeypatch):
     """Two passes over the same input give the same bits on every kernel family at a chip-filling size (32 x 256 x 256): no
     kernel depends on workgroup timing.  (Round 4 met two variants that passed every oracle tolerance and were not repeatable -
-    a 6-deep weight ring in the two-term direct kernel, a separable upsample in its 4 x 2 tile; neither is in the tree.)"""
+    a separable upsample interpolation in the bf16 direct kernel's 4 x 2 tile and the same in the producer waves of
+    conv3x3_bf16ws_kernel; neither is in the tree, profiles/r04_ablation.md.)"""
     from dt4image_restoration_amd.engine import PnPEngine
     n, h, w = 32, 256, 256
     if mode == "bf16-direct-kernels":
@@ -403,5 +404,27 @@ def test_denoiser_passes_are_bit_repeatable(sd_np, mode, monkeypatch):
     x = ((torch.from_numpy(synthetic.hash_uniform(31, 7, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
     sigma = (torch.linspace(4, 55, n) / 255.0).cuda()
     first = e.denoise(x, sigma).clone()
-    for _ in range(3):
+    for _ in range(40):                                     # (a pass is ~5 ms; the race this caught in round 4 showed once in dozens of passes)
         assert torch.equal(e.denoise(x, sigma), first)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128), (5, 256, 256), (3, 96, 80)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_splitk_inlaunch_combine_is_bit_identical(sd_np, shape, bf16, monkeypatch):
+    """PNP_SPLITK_INLAUNCH=1 (small problems): the split-K planes are summed inside the conv launch by the last workgroup of a
+    tile to arrive - agent-scope stores / loads around one relaxed atomic, no fence - in the plane order of splitk_reduce_kernel:
+    the same bits as the two-launch path, pass after pass."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    n, h, w = shape
+    x = ((torch.from_numpy(synthetic.hash_uniform(57, 3, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
+    sigma = (torch.linspace(6, 50, n) / 255.0).cuda()
+    ref_engine = PnPEngine(n, h, w, bf16_convs=bf16)
+    ref_engine.load_weights(sd_np)
+    assert 0 in ref_engine.conv_algorithms()                # some layers run the direct kernel (split-K on these sizes)
+    want = ref_engine.denoise(x, sigma).clone()
+    monkeypatch.setenv("PNP_SPLITK_INLAUNCH", "1")
+    e = PnPEngine(n, h, w, bf16_convs=bf16)
+    monkeypatch.delenv("PNP_SPLITK_INLAUNCH")
+    e.load_weights(sd_np)
+    for _ in range(25):
+        assert torch.equal(e.denoise(x, sigma), want)
