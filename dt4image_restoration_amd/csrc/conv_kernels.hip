@@ -71,8 +71,8 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src
     // v_mfma_f32_32x32x2_f32 = 7.7 us - on a chip with most SIMDs idle, so the f32 plan cuts finer: one 32-pixel M-block per
     // wave and 16-channel chunks (72 MFMAs per chunk, twice the tiles, twice the K ranges): 20 -> 14 us per layer at
     // 1 x 128 x 128 (profiles/r04_ablation.md).  (bf16 k-steps are sixteen times shorter; that mode keeps the round-3 tiles.)
-    // The upsample + concat layers keep the round-3 tile (their chain is the two-stage staging, not the MFMAs: no gain measured), and
-    // 384 workgroups stays the target (256: -10 % at 5 x 256 x 256).
+    // The upsample + concat layers keep the round-3 tile and its 384-workgroup rule (their chain is the two-stage staging, not the
+    // MFMAs: no gain measured).
     static const bool coarse = getenv("PNP_SPLITK_COARSE") != nullptr;       // (A/B: the round-3 tiles)
     const bool fine = !coarse && !bf16;
     if (blocks < 128 && Cout >= 64) {
@@ -84,6 +84,20 @@ ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16, int src
         int sk = (int)((384 + blocks - 1) / blocks);
         if (sk > nchunks) sk = nchunks;
         while (nchunks % sk != 0) --sk;             // equal ranges
+        if (f) {
+            // K ranges by a makespan model fitted to per-layer timings (MI355X, 1 ... 8 slices of 128 x 128 ... 512 x 512): a workgroup
+            // alone on its CU takes ~5.2 us per 16-channel chunk (one wave's dependent MFMA chain + an exposed staging round trip),
+            // k co-resident ones ~3.3 us each per chunk (the pipe is shared); every K range writes and re-reads one plane (~5 TB/s,
+            // mostly L2 / MALL hits)
+            const float plane_us = (float)pixels * (float)Cout * 4.f * 2.f / 5.0e6f;
+            float best = 1e30f;
+            for (int d = 1; d <= nchunks; ++d) {
+                if (nchunks % d != 0) continue;
+                const float k = (float)((blocks * d + 255) / 256);
+                const float cost = (float)(nchunks / d) * fmaxf(5.2f, 3.3f * k) + (float)d * plane_us;
+                if (cost < best * 0.97f) { best = cost; sk = d; }
+            }
+        }
         p.splitk = sk;
     } else if (blocks <= 128 && Cout == 32 && fine) {
         p.mt = 1;                                   // 128-pixel tiles (LDS epilogue, pooled copy and fused last layer as on the 256-pixel tile)
