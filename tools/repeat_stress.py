@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""GPU box: are denoiser passes and whole ADMM steps bit-repeatable on every kernel family at the benchmark sizes?  (Round 4 met a race
+that showed once in dozens of passes - tests/test_gpu_kernels.py::test_denoiser_passes_are_bit_repeatable is the short form of this.)
+
+    python tools/repeat_stress.py [--passes 300] [--sizes 64x256x256,...] [--modes f32,bf16,...]
+
+one JSON line per (mode, size); exit code 1 on any mismatch.  PNP_LIB_PATH selects another build of the library.
+"""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dt4image_restoration_amd import synthetic, weights  # noqa: E402
+from dt4image_restoration_amd.engine import PnPEngine     # noqa: E402
+
+MODES = {  # name -> (bf16_convs, environment while the handle is created)
+    "f32": (False, {}),
+    "bf16": (True, {}),
+    "bf16-direct-kernels": (True, {"PNP_BF16_NO_WS": "1"}),
+    "bf16-one-term": (True, {"PNP_BF16_W1": "1"}),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--passes", type=int, default=300)
+    ap.add_argument("--sizes", default="64x256x256,16x512x512,5x256x256,1x128x128")
+    ap.add_argument("--modes", default=",".join(MODES))
+    args = ap.parse_args()
+    sd = weights.generate_unet_weights(0, "unit_gain")
+    bad = 0
+    for size in args.sizes.split(","):
+        n, h, w = (int(v) for v in size.split("x"))
+        x = ((torch.from_numpy(synthetic.hash_uniform(31, 7, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
+        sigma = (torch.linspace(4, 55, n) / 255.0).cuda()
+        data = synthetic.make_problem(n, h, w, accel=4.0, sigma_n=10.0 / 255.0, seed=1234)
+        mu_tab, sg_tab = synthetic.param_table(n, 4, seed=77)
+        for mode in args.modes.split(","):
+            bf16, env = MODES[mode]
+            os.environ.update(env)
+            e = PnPEngine(n, h, w, bf16_convs=bf16)
+            for k in env:
+                del os.environ[k]
+            e.load_weights(sd)
+            t0 = time.time()
+            first = e.denoise(x, sigma).clone()
+            miss = 0
+            for _ in range(args.passes):
+                miss += int(not torch.equal(e.denoise(x, sigma), first))
+            # whole steps (denoiser + data-fidelity passes + dual update), 4 iterations from reset, repeated
+            x0 = torch.view_as_complex(torch.from_numpy(data["x0"])).cuda()
+            y0 = torch.view_as_complex(torch.from_numpy(data["y0"])).cuda()
+            mask = torch.from_numpy(data["mask"]).cuda()
+            mu = torch.from_numpy(mu_tab).cuda().t().contiguous()
+            sg = torch.from_numpy(sg_tab).cuda().t().contiguous()
+            want, smiss = None, 0
+            for _ in range(max(args.passes // 10, 3)):
+                xs, zs, us = e.reset(x0, y0, mask)
+                for t in range(4):
+                    e.step(xs, zs, us, mu[t], sg[t])
+                got = (xs.clone(), torch.view_as_real(zs).clone(), torch.view_as_real(us).clone())
+                if want is None:
+                    want = got
+                else:
+                    smiss += int(not all(torch.equal(a, b) for a, b in zip(got, want)))
+            torch.cuda.synchronize()
+            print(json.dumps({"size": size, "mode": mode, "denoiser_passes": args.passes, "passes_that_differed": miss,
+                              "episodes_of_4_steps": max(args.passes // 10, 3), "episodes_that_differed": smiss,
+                              "seconds": round(time.time() - t0, 1)}), flush=True)
+            bad += miss + smiss
+            del e
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
