@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     // in slot j % PFD; a bf16 k-step is only MT*NT*32 cycles of MFMA, so the small tiles look 9 k-steps ahead.
     // (two-term weights: a slot holds two fragments and a k-step is twice as long - 6 slots cover the latency 9 did and the
     // three-workgroups-per-CU variants stop spilling)
-    constexpr int PFD = BF16 ? (MT * NT <= 2 ? (NW == 2 ? 6 : 9) : 3) : 2;
+    // (the upsample + concat variant on bf16 activations - up4.conv-0 - runs three workgroups per CU since late round 4: its staging is a
+    // chain of LDS round trips that only more waves hide, 0.618 -> 0.536 ms at 16 x 512 x 512; three slots keep it at 157 registers)
+    constexpr int PFD = BF16 ? (MT * NT <= 2 ? (NW == 2 ? ((SRC == SRC_UPCAT && A16) ? 3 : 6) : 9) : 3) : 2;
     static_assert(KS % PFD == 0, "slot rotation must line up at chunk boundaries");
     constexpr int PPP = CK / 4;        // 16-byte pieces per pixel
     constexpr int BM = WM * MT * 32;   // pixels per workgroup tile
@@ -700,13 +702,15 @@ template <int TW, int MT, int NT, int WM, int WN, int CK, int SRC, bool SPLITK, 
 static hipError_t launch_inst(const ConvArgs& a, const ConvPlan& p, hipStream_t s) {
     // registers: 16*MT*NT accumulators + operands + staging: 32 acc -> 3 waves per SIMD, 128 -> 2, 256 -> 1
     // (the UPCAT variant also holds the low-res source region in LDS and a prefetched skip chunk in registers: two
-    // workgroups per CU; three with the bf16 patch measured 8 % slower on up4.conv-0, it spills 54 registers)
+    // workgroups per CU; three with the bf16 patch measured 8 % slower on up4.conv-0 in round 2, when it spilled 54 registers - on
+    // bf16 activations and a three-slot weight ring it fits 157 and is 13 % FASTER: WPS16)
     constexpr int WPS = (MT * NT <= 2 && SRC != SRC_UPCAT) ? 3 : (MT * NT <= 8 ? 2 : 1);
+    constexpr int WPS16 = (MT * NT <= 2 && BF16 == 2) ? 3 : WPS;      // bf16 activations, two-term weights: the UPCAT variant too
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * a.N), (unsigned)(a.Cout / p.bn), (unsigned)p.splitk);
     constexpr bool CAN16 = BF16 != 0 && !SPLITK && MT == 2 && NT == 1 && WM == 4 && CK == 32 && SRC != SRC_POOL;
     if constexpr (CAN16) {
         if (a.act16 & 1) {
-            hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS, SPLITK, BF16, true>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MT, NT, WM, WN, CK, SRC, WPS16, SPLITK, BF16, true>), grid, dim3(256), 0, s, a);
             return hipGetLastError();
         }
     }
