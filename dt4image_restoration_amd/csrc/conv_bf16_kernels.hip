@@ -46,7 +46,7 @@ template <int TW, int WM, int MT, int NT, int SRC>
 constexpr int bf16ws_lds_floats() {
     constexpr int TH = WM * MT * 32 / TW, PH = TH + 2, PW = TW + 2;
     return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0) +
-           (NT == 1 ? WM * MT * 32 * 36 : 4 * 32 * (NT * 16 + 4)) + 256;         // + the stopped-tile flags
+           (NT == 1 ? 2 * WM * MT * 32 * 36 : 4 * 32 * (NT * 16 + 4)) + 256;     // (NT = 1: two output tiles, see OFFLOAD) + the stopped-tile flags
 }
 
 // A16S: src0 (the PLAIN / POOL source, the UPCAT skip tensor) holds bf16 - written so by the launch that produced it, rounded
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     // ... - are fetched once into LDS: a read of tact[] per tile is a memory round trip in both roles' critical paths, and
     // a 32-channel tile is only ~2 us of work.
     constexpr int MAXLIVE = 256;
-    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? BM * 36 : 4 * 32 * (NT * 16 + 4)));
+    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? 2 * BM * 36 : 4 * 32 * (NT * 16 + 4)));
     const int mine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
     const bool cached = a.tact != nullptr && mine <= MAXLIVE;
     if (cached) {
@@ -176,6 +176,62 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     int t = next_live((int)blockIdx.x);
     if (t >= total) return;             // (both roles agree: no barrier is ever reached)
     WS_STAMP(wid >= 4);
+
+    // OFFLOAD (the 32 -> 32 layers, one chunk per tile: item g IS tile g): the consumers only write their LeakyReLU'd f32 tile into
+    // epi[g & 1] and go on to the next tile's k-loop; the tile's read-back, converts, 16-byte stores and pooled copy - 1100-1900 of the
+    // 5300 cycles of a tile on the one consumer wave of a SIMD (`profiles/r04_bf16ws_stamps_final.txt`) - are done by the PRODUCER wave of
+    // the same SIMD in the next interval (it has ~4000 idle cycles per item on these layers): epi[g & 1] is complete at barrier #(g + 1),
+    // read before barrier #(g + 2), rewritten after it.
+    constexpr bool OFFLOAD = HOLDHI;
+    auto store_tile = [&](const float* et, int w4, int n, int ty0, int tx0) __attribute__((always_inline)) {   // wave w4's two rows of the tile at et
+        constexpr int OSTR = 36, WPX = MT * 32;
+        auto act4 = [](float4 v) {                         // LeakyReLU(0.2) of the raw sums the consumers left
+            return make_float4(fmaxf(v.x, kLeaky * v.x), fmaxf(v.y, kLeaky * v.y), fmaxf(v.z, kLeaky * v.z), fmaxf(v.w, kLeaky * v.w));
+        };
+        const float* const ew = et + w4 * WPX * OSTR;
+        const int wy0 = ty0 + w4 * (WPX / TW);
+        if (a.act16 & 2) {                                  // bf16 dst: 8 channels (16 B) per lane, 64 B per pixel
+            uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
+#pragma unroll
+            for (int j = 0; j < WPX * 4 / 64; ++j) {
+                const int f = lane + 64 * j, px = f / 4, c8 = f % 4;
+                const int gy = wy0 + px / TW, gx = tx0 + px % TW;
+                if (gy < a.H && gx < a.W) {
+                    const float4 v0 = act4(*reinterpret_cast<const float4*>(&ew[px * OSTR + 8 * c8]));
+                    const float4 v1 = act4(*reinterpret_cast<const float4*>(&ew[px * OSTR + 8 * c8 + 4]));
+                    uint4 o;
+                    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.x, v0.y}, bf16x2));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0.z, v0.w}, bf16x2));
+                    o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.x, v1.y}, bf16x2));
+                    o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v1.z, v1.w}, bf16x2));
+                    *reinterpret_cast<uint4*>(d16 + (((size_t)n * a.H + gy) * a.W + gx) * 32 + 8 * c8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WPX * 8 / 64; ++j) {
+                const int f = lane + 64 * j, px = f / 8, c4 = f % 8;
+                const int gy = wy0 + px / TW, gx = tx0 + px % TW;
+                if (gy < a.H && gx < a.W)
+                    *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * 32 + 4 * c4) =
+                        act4(*reinterpret_cast<const float4*>(&ew[px * OSTR + 4 * c4]));
+            }
+        }
+        if (a.pooled != nullptr) {                         // MaxPool2d(2) of the wave's two rows, f32 (its reader rounds after)
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+            for (int j = 0; j < (TW / 2) * 8 / 64; ++j) {
+                const int f = lane + 64 * j, qx = f / 8, c4 = f % 8;
+                const int gy = (wy0 >> 1), gx = (tx0 >> 1) + qx;
+                if (gy < Hp && gx < Wp) {
+                    const float* o = &ew[(2 * qx) * OSTR + 4 * c4];
+                    const float4 m = act4(f4max(f4max(*reinterpret_cast<const float4*>(o), *reinterpret_cast<const float4*>(o + OSTR)),        // (monotonic:
+                                                f4max(*reinterpret_cast<const float4*>(o + TW * OSTR), *reinterpret_cast<const float4*>(o + TW * OSTR + OSTR))));   // = max of the activations)
+                    *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * 32 + 4 * c4) = m;
+                }
+            }
+        }
+    };
 
     if (wid >= 4) {
         // ---------------------------------------------------------------- producers ----------------------------
@@ -369,6 +425,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             t = t1; c = c1; ++pending;
         };
         int meta0 = 0, meta1 = 0;
+        int gp = 0;                                            // items committed = barriers passed
+        int ts = t;                                            // OFFLOAD: the tile whose output the consumers finish next (their sequence)
+        auto store_prev = [&]() __attribute__((always_inline)) {     // OFFLOAD, after barrier #gp' (gp' = gp - 1 >= 1): tile gp' - 1 is complete in epi
+            const TileAt ta = tile_at(ts);
+            store_tile(epi + ((gp - 2) & 1) * (BM * 36), wid - 4, ta.n, ta.ty0, ta.tx0);
+            ts = next_live(ts + (int)gridDim.x);
+        };
         auto step = [&](RawSet& raw, int& meta, float* buf) {
             commit(buf, raw, meta);
             WS_STAMP(1);
@@ -377,6 +440,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             WS_STAMP(1);
             __syncthreads();                                   // barrier #g
             WS_STAMP(1);
+            ++gp;
+            if constexpr (OFFLOAD) { if (gp >= 2) store_prev(); }
             return pending > 0;
         };
         issue_next(raw0, meta0, true);
@@ -392,6 +457,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 if (!step(raw0, meta0, patch)) break;
                 if (!step(raw0, meta0, patch + PATCH)) break;
             }
+        }
+        if constexpr (OFFLOAD) {
+            __syncthreads();                                   // the consumers' last tile is in epi
+            ++gp;
+            store_prev();
         }
         return;
     }
@@ -439,11 +509,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     }
     int g = 0;
     WS_STAMP(0);
+    // 32-channel tile: the NEXT tile's decode (five reciprocal divisions, ~500 cycles of a 4500-cycle tile at the top of the loop) is
+    // computed inside this tile's k-loop, in the shadow of its MFMAs
+    constexpr bool DECODE_AHEAD = NT == 1;
+    TileAt ta_c = tile_at(t), ta_nx = ta_c;
+    int wt_c = wbase(t), wt_nx = wt_c;
     while (t < total) {
-        const TileAt ta = tile_at(t);
+        const TileAt ta = DECODE_AHEAD ? ta_c : tile_at(t);
         const int cbt = ta.cb, tx0 = ta.tx0, ty0 = ta.ty0, n = ta.n;
         const int t_next = next_live(t + (int)gridDim.x);      // (its loads fly under this tile's k-loops)
-        const int wtile = wbase(t);
+        const int wtile = DECODE_AHEAD ? wt_c : wbase(t);
         f32x16 acc[MT][NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -470,6 +545,15 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (UP2 && ks == XK && park) __syncthreads();  // barrier X (see the producers' commit)
+                if constexpr (DECODE_AHEAD) {
+                    if (ks == 2 && c == 0) {
+                        const int tn = t_next < total ? t_next : t;
+                        const TileAt q = tile_at(tn);
+                        ta_nx.cb = __builtin_amdgcn_readfirstlane(q.cb); ta_nx.n = __builtin_amdgcn_readfirstlane(q.n);
+                        ta_nx.ty0 = __builtin_amdgcn_readfirstlane(q.ty0); ta_nx.tx0 = __builtin_amdgcn_readfirstlane(q.tx0);
+                        wt_nx = __builtin_amdgcn_readfirstlane(wbase(tn));
+                    }
+                }
                 float4 a1[MT];
                 if (ks + 1 < KS) {                             // A fragments of the next k-step
                     const int tap1 = (ks + 1) / (CK / 16), s1 = (ks + 1) % (CK / 16);
@@ -521,17 +605,21 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             // the next stage (noise.py:22-25) or the fused last layer (1x1 conv 32 -> 1 + image residual + clamp, noise.py:67,
             // 130-133,164; this conv's own output is then never written) come from the same tile
             constexpr int OSTR = 36, WPX = MT * 32;            // a wave's pixels: WPX / TW = 2 whole tile rows
-            float* const ew = epi + wid * WPX * OSTR;
+            float* const ew = epi + (OFFLOAD ? ((g - 1) & 1) * (BM * 36) : 0) + wid * WPX * OSTR;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ew[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * OSTR + li] = fmaxf(acc[mt][0][r], kLeaky * acc[mt][0][r]);
+                    ew[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * OSTR + li] =
+                        OFFLOAD ? acc[mt][0][r] : fmaxf(acc[mt][0][r], kLeaky * acc[mt][0][r]);   // (OFFLOAD: the activation is applied by store_tile)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             WS_STAMP(0);                                       // (diagnostic build: output tile written to LDS)
             const int wy0 = ty0 + wid * (WPX / TW);            // the wave's first image row
+            if constexpr (OFFLOAD) {
+                // stored by producer wave wid + 4 after the next workgroup barrier (store_tile above)
+            } else
             if (a.last_w != nullptr) {
                 const int gy = wy0 + lane / TW, gx = tx0 + lane % TW;          // one pixel per lane
                 if (gy < a.H && gx < a.W) {
@@ -660,7 +748,9 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         }
         WS_STAMP(0);
         t = t_next;
+        ta_c = ta_nx; wt_c = wt_nx;
     }
+    if constexpr (OFFLOAD) __syncthreads();                    // hands the last tile to the producers
 }
 
 template <int TW, int WM, int WN, int MT, int NT, int SRC, bool A16S, int NW, bool HOLDHI = false>
