@@ -46,7 +46,8 @@ template <int TW, int WM, int MT, int NT, int SRC>
 constexpr int bf16ws_lds_floats() {
     constexpr int TH = WM * MT * 32 / TW, PH = TH + 2, PW = TW + 2;
     return 2 * PH * PW * 20 + (SRC == SRC_UPCAT ? (TH / 2 + 3) * (TW / 2 + 3) * 36 + 2 * 4 * (PH + PW) : 0) +
-           (NT == 1 ? 2 * WM * MT * 32 * 36 : 4 * 32 * (NT * 16 + 4)) + 256;     // (NT = 1: two output tiles, see OFFLOAD) + the stopped-tile flags
+           (NT == 1 ? 2 * WM * MT * 32 * 36 : 4 * 32 * (SRC == SRC_UPCAT ? NT * 16 + 4 : NT * 32 + 4)) + 256;   // (NT = 1: two output tiles, see OFFLOAD;
+                                                             // else the epilogue's staging slices, f32-sized where the source leaves the LDS for it) + the stopped-tile flags
 }
 
 // A16S: src0 (the PLAIN / POOL source, the UPCAT skip tensor) holds bf16 - written so by the launch that produced it, rounded
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     // ... - are fetched once into LDS: a read of tact[] per tile is a memory round trip in both roles' critical paths, and
     // a 32-channel tile is only ~2 us of work.
     constexpr int MAXLIVE = 256;
-    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? 2 * BM * 36 : 4 * 32 * (NT * 16 + 4)));
+    int* const stopped = reinterpret_cast<int*>(epi + (NT == 1 ? 2 * BM * 36 : 4 * 32 * (SRC == SRC_UPCAT ? NT * 16 + 4 : NT * 32 + 4)));
     const int mine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
     const bool cached = a.tact != nullptr && mine <= MAXLIVE;
     if (cached) {
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
     WS_STAMP(0);
     // 32-channel tile: the NEXT tile's decode (five reciprocal divisions, ~500 cycles of a 4500-cycle tile at the top of the loop) is
     // computed inside this tile's k-loop, in the shadow of its MFMAs
-    constexpr bool DECODE_AHEAD = NT == 1;
+    constexpr bool DECODE_AHEAD = NT == 1;       // (on the 4 x 2 tiles: +0.2...0.5 %, inside the noise, for 5-20 more spilled SGPRs - not taken)
     TileAt ta_c = tile_at(t), ta_nx = ta_c;
     int wt_c = wbase(t), wt_nx = wt_c;
     while (t < total) {
@@ -724,6 +725,35 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                     const uint4 v = *reinterpret_cast<const uint4*>(&st[pl * SSTR + c8 * 4]);
                     if (gy < a.H && gx < a.W)
                         *reinterpret_cast<uint4*>(d16 + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cw0 + 8 * c8) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);             // (the next M-block's LDS writes follow these reads in program order)
+            }
+        } else if (SRC != SRC_UPCAT) {
+            // f32 dst (the layers whose output is the low-res source of an upsample: it stays f32, its reader rounds after interpolating), the
+            // same way: one M-block at a time through this wave's staging slice, out as 16-byte stores over whole 256-byte channel runs
+            // (4-byte stores on 128-byte fragments made this epilogue 12800 cycles against the bf16 one's 6900, `r04_bf16ws_stamps_final.txt`)
+            constexpr int SSTRF = NT * 32 + 4;                 // staged pixel: NT * 128 bytes of channels + 16 bytes of skew, in floats
+            constexpr int CPPF = NT * 8;                       // 16-byte pieces per staged pixel
+            float* const stf = epi + wid * (32 * SSTRF);
+            const int cw0 = (cbt * (WN * NT) + wn * NT) * 32;  // this wave's first output channel
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stf[((r & 3) + 8 * (r >> 2) + 4 * hh) * SSTRF + nt * 32 + li] = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 32 * CPPF / 64; ++i) {
+                    const int f = lane + 64 * i, pl = f / CPPF, c4 = f % CPPF;
+                    const int q = (wm * MT + mt) * 32 + pl;
+                    const int gy = ty0 + q / TW, gx = tx0 + q % TW;
+                    const float4 v = *reinterpret_cast<const float4*>(&stf[pl * SSTRF + c4 * 4]);
+                    if (gy < a.H && gx < a.W)
+                        *reinterpret_cast<float4*>(a.dst + (((size_t)n * a.H + gy) * a.W + gx) * a.Cout + cw0 + 4 * c4) = v;
                 }
                 __builtin_amdgcn_sched_barrier(0);             // (the next M-block's LDS writes follow these reads in program order)
             }
