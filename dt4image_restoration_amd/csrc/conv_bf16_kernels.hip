@@ -18,7 +18,8 @@
 //                   producers  wait loads(k) - write buffer k&1 - issue loads(k+2) into the register set just freed
 //     barrier #k :  buffer k&1 is complete; buffer (k-1)&1 is free
 // An "item" is one (tile, 32-channel chunk); a workgroup walks tiles blockIdx.x, + gridDim.x, ... (persistent, one per CU),
-// so the producers are already fetching the next tile while the consumers store this one.
+// so the producers are already fetching the next tile while the consumers store this one.  (On the 32 -> 32 layers the producers
+// store the tiles as well - OFFLOAD below - and the consumers hold the layer's weights in registers - HOLDHI.)
 #include "pnp_internal.h"
 #include "conv_staging.h"
 #include <cstdlib>
@@ -191,6 +192,24 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         };
         const float* const ew = et + w4 * WPX * OSTR;
         const int wy0 = ty0 + w4 * (WPX / TW);
+        if (a.last_w != nullptr) {
+            // fused last layer (noise.py:67,130-133,164): 1x1 conv 32 -> 1 + image residual + clamp; this conv's own output is never
+            // written.  One pixel per lane, the sums in the order of the consumers' form of it (below) and of conv_kernels.hip.
+            const int gy = wy0 + lane / TW, gx = tx0 + lane % TW;
+            if (gy < a.H && gx < a.W) {
+                float dsum = a.last_b[0];
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 v = act4(*reinterpret_cast<const float4*>(&ew[lane * OSTR + 4 * c4]));
+                    const float4 wv = *reinterpret_cast<const float4*>(a.last_w + 4 * c4);
+                    dsum += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                }
+                const size_t q = ((size_t)n * a.H + gy) * a.W + gx;
+                const float img = a.last_ximg != nullptr ? a.last_ximg[q] : (a.last_z[q].x - a.last_u[q].x);
+                a.last_out[q] = fminf(fmaxf(img + dsum, 0.f), 1.f);
+            }
+            return;
+        }
         if (a.act16 & 2) {                                  // bf16 dst: 8 channels (16 B) per lane, 64 B per pixel
             uint16_t* const d16 = reinterpret_cast<uint16_t*>(a.dst);
 #pragma unroll
