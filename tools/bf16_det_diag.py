@@ -20,11 +20,20 @@ for rep in range(4):
     else:
         print("rep", rep, "stage diffs:", [int((a != b).sum()) for a, b in zip(st, ref)])
     if rep == 1:
-        d = (st[5] != ref[5])            # [n, C, h, w] of the first upsample stage
-        if int(d.sum()) > 0:
+        first = next((k for k in range(9) if int((st[k] != ref[k]).sum()) > 0), None)
+        if first is not None:
+            d = (st[first] != ref[first])            # [n, C, h, w] of the first stage that differs
             nn, cc, yy, xx = torch.nonzero(d, as_tuple=True)
-            print(" y % 8 histogram", torch.bincount(yy % 8, minlength=8).tolist())
+            print(" first differing stage", first, "shape", tuple(d.shape))
+            print(" y % 16 histogram", torch.bincount(yy % 16, minlength=16).tolist())
             print(" x % 32 histogram", torch.bincount(xx % 32, minlength=32).tolist())
             print(" channel % 32 histogram", torch.bincount(cc % 32, minlength=32).tolist())
             print(" channel // 32 histogram", torch.bincount(cc // 32, minlength=8).tolist())
-            print(" slices affected", len(torch.unique(nn)), "max abs", float((st[5] - ref[5]).abs().max()), "ref max", float(ref[5].abs().max()))
+            print(" y // 16 histogram", torch.bincount(yy // 16).tolist())
+            print(" x // 16 histogram", torch.bincount(xx // 16).tolist())
+            n0 = int(nn[0]); sel = (nn == n0) & (cc == int(cc[0]))
+            pts = sorted(set(zip(yy[sel].tolist(), xx[sel].tolist())))
+            print(" slice", n0, "channel", int(cc[0]), "differing pixels (y, x):", pts[:80])
+            dd = (st[first] - ref[first])[n0, int(cc[0])]
+            print(" their differences:", [round(float(dd[y, x]), 5) for y, x in pts[:40]])
+            print(" slices affected", len(torch.unique(nn)), "max abs", float((st[first] - ref[first]).abs().max()), "ref max", float(ref[first].abs().max()))
