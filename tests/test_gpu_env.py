@@ -313,7 +313,9 @@ def test_bf16_batch64_plan_matches_bf16_oracle_and_skips_stopped_slices(denoiser
     e = PnPEngine(n, h, w, bf16_convs=True)
     e.load_weights(denoiser.weights)
     algos = e.conv_algorithms()
-    assert [li for li in range(1, 27) if algos[li] != 5] == [24], algos          # up4.conv-0 stays on conv_kernels.hip (three workgroups per CU)
+    # up4.conv-0 stays on conv_kernels.hip (three workgroups per CU); so does the fused last layer when the 32 -> 32 layers do not hold their weights
+    expected = [24, 26] if os.environ.get("PNP_BF16_NO_HOLDHI") else [24]
+    assert [li for li in range(1, 27) if algos[li] != 5] == expected, algos
     sd = O.torch_weights(denoiser.weights)
     x = ((torch.from_numpy(synthetic.hash_uniform(9, 64256, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5)
     sigma = torch.linspace(3, 60, n) / 255.0
