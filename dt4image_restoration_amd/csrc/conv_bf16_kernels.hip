@@ -303,13 +303,18 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
             }
             if constexpr (UP2) {
                 const int Hl = a.H >> 1, Wl = a.W >> 1, Cup = a.Cin - a.Cskip;
+#ifndef PNP_WS_NO_SEP
+                const int ylo = ty0 / 2 - 1;                   // separable form: patch row pq interpolates lines ylo + (pq >> 1) and the next one
+                const int xlo = (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0));
+#else
                 const int ylo = (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)), xlo = (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0));
+#endif
                 const size_t sl = (size_t)Hl * Wl * Cup;
                 rsrcL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 + (size_t)n * sl), 0, (int)(sl * sizeof(float)), 0x00020000);
 #pragma unroll
                 for (int k = 0; k < NITL; ++k) {
                     const int sy = ylo + (lyx[k] >> 16), sx = xlo + (lyx[k] & 0xffff);
-                    goffL[k] = (lyx[k] >= 0 && sy < Hl && sx < Wl) ? (unsigned)((sy * Wl + sx) * Cup + part * 4) * 4u : 0x80000000u;
+                    goffL[k] = (lyx[k] >= 0 && sy >= 0 && sy < Hl && sx < Wl) ? (unsigned)((sy * Wl + sx) * Cup + part * 4) * 4u : 0x80000000u;
                 }
                 // this tile's interpolation table (ATen upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1),
                 // weights (1-l, l)); a row / column outside the image gets zero weights on line 0 = the conv's zero padding.
@@ -327,6 +332,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                         const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
                         const int lo = isrow ? ylo : xlo, mul = isrow ? LW * CKL : CKL;
                         e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+#ifndef PNP_WS_NO_SEP
+                        if (isrow) {                           // {weight of line s0, weight of line s0 + 1}: upsample_lines_regular(), as in the F(4x4) kernels
+                            const int s0 = ylo + (pq >> 1);
+                            e = make_float4((i0 == s0 ? 1.f - l : 0.f) + (i1 == s0 ? l : 0.f), (i0 == s0 + 1 ? 1.f - l : 0.f) + (i1 == s0 + 1 ? l : 0.f), 0.f, 0.f);
+                        }
+#endif
                     }
                     *reinterpret_cast<float4*>(&tabs[tile_par * 4 * (PH + PW) + 4 * ptid]) = e;
                 }
@@ -374,6 +385,59 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                         if (p0 + 32 * k < LH * LW) *reinterpret_cast<float4*>(&lowres[(p0 + 32 * k) * CKL + part * 4]) = raw[k][0];
                     __syncthreads();                           // barrier X: the region is parked (its readers are these four waves)
                     const float* tb = tabs + (meta >> 1) * 4 * (PH + PW);
+#ifndef PNP_WS_NO_SEP
+                    {
+                        // Separable form (late round 4; the producers' interpolation is bound by vector issue, `profiles/r04_ablation.md`): a task is
+                        // (group of 6 patch rows, patch column, 4-channel part); the horizontal lerps of the four source lines the group touches
+                        // are done once, in registers, and each row is then ONE vertical lerp of two of them - a third of the 4-tap form's
+                        // instructions.  Needs the regular line structure of upsample_lines_regular() (pnp_create keeps other heights off this kernel).
+                        //
+                        // The vertical lerp is written in non-packed instructions ON PURPOSE.  What hipcc makes of the plain expression - v_pk_mul_f32 /
+                        // v_pk_fma_f32 with op_sel swizzles, the destination pair overlapping the row-weight pair, two v_cvt_pk_bf16_f32, ds_write_b64, and
+                        // the next row's ds_read_b64 into the registers just stored - produced, in this kernel (a consumer wave issuing MFMAs on the same
+                        // SIMD), results that differed from pass to pass in one channel of a piece: 998 of 1000 passes, 0 of 600 with the four
+                        // lines below (and 0 in a stand-alone probe without MFMA traffic, exp/ds_write_hazard.hip).  Three bf16 separable variants
+                        // of this round died of it before it was pinned down.
+                        auto lerp1 = [](float wa, float a_, float wb, float b_) {
+                            float t, r;
+                            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(wa), "v"(a_));
+                            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(wb), "v"(b_), "v"(t));
+                            return r;
+                        };
+                        constexpr int NG = (PH + 5) / 6;               // row groups of six (the last one may be short)
+                        static_assert(3 * (NG - 1) + 3 < LH, "a group's four source lines are inside the parked region");
+                        constexpr int TPG = PW * PPP, TASKS = NG * TPG, ROUNDS = (TASKS + 255) / 256;
+#pragma unroll 1
+                        for (int rd = 0; rd < ROUNDS; ++rd) {
+                            const int T = ptid + 256 * rd;
+                            if (T < TASKS) {
+                                const int rg = T / TPG, rest = T - rg * TPG, px = rest / PPP, pt = rest % PPP;
+                                const float4 ct = *reinterpret_cast<const float4*>(&tb[4 * (PH + px)]);
+                                const float* l0 = &lowres[(3 * rg) * (LW * CKL) + pt * 4];
+                                const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
+                                float4 h[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float4 u = *reinterpret_cast<const float4*>(l0 + j * (LW * CKL) + c0);
+                                    const float4 v = *reinterpret_cast<const float4*>(l0 + j * (LW * CKL) + c1);
+                                    h[j] = make_float4(ct.z * u.x + ct.w * v.x, ct.z * u.y + ct.w * v.y, ct.z * u.z + ct.w * v.z, ct.z * u.w + ct.w * v.w);
+                                }
+                                float* const dst = &buf[((6 * rg) * PW + px) * CKP + pt * 2];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) {
+                                    const bool rok = 6 * rg + i < PH;
+                                    const float2 rw = *reinterpret_cast<const float2*>(&tb[4 * (rok ? 6 * rg + i : PH - 1)]);
+                                    const float4 &ha = h[i >> 1], &hb = h[(i >> 1) + 1];
+                                    const float4 o = make_float4(lerp1(rw.x, ha.x, rw.y, hb.x), lerp1(rw.x, ha.y, rw.y, hb.y), lerp1(rw.x, ha.z, rw.y, hb.z), lerp1(rw.x, ha.w, rw.y, hb.w));
+                                    const bf16x2 lo = __builtin_convertvector((f32x2){o.x, o.y}, bf16x2);
+                                    const bf16x2 hi = __builtin_convertvector((f32x2){o.z, o.w}, bf16x2);
+                                    if (rok) *reinterpret_cast<uint2*>(dst + i * (PW * CKP)) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+                                }
+                            }
+                        }
+                        return;
+                    }
+#endif
                     // Pieces in groups of G: all table entries, then all source pieces, then the arithmetic and the stores - a piece is
                     // two dependent LDS round trips (~350 cycles each under the consumers' load), and one piece at a time is 8200
                     // cycles per item (`profiles/r03_bf16ws_stamps.txt`), nearly twice the consumers' k-loop.  (An LDS store between

@@ -335,7 +335,9 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
                 t2.no_f4 = true;
                 e->wplan[li] = winograd_plan(cfg->n, lh, lw, L.cin, L.cout, src_mode, t2);
             }
-            e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, !e->tune.bf16_no_ws);
+            // (the producer / consumer kernel's upsample is the separable form: only on heights with the regular line structure)
+            const bool ws_ok = !e->tune.bf16_no_ws && (src_mode != SRC_UPCAT || upsample_lines_regular(lh));
+            e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, ws_ok);
             // up4.conv-2 (fused last layer): on the producer / consumer kernel only in the two-term mode, where its producers evaluate the last
             // layer (OFFLOAD); the one-term form of that tile measured slower than conv_kernels.hip (conv3x3_plan)
             if (li == 26 && e->cplan[li].nt == 1 && (e->bf16_terms != 2 || getenv("PNP_BF16_NO_HOLDHI") != nullptr)) e->cplan[li].ws = 0;
