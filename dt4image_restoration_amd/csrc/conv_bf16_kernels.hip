@@ -438,6 +438,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                         return;
                     }
 #endif
+                    // The 4-tap form of rounds 3-4 (reached only in a -DPNP_WS_NO_SEP build: the A/B baseline of the separable form above).
                     // Pieces in groups of G: all table entries, then all source pieces, then the arithmetic and the stores - a piece is
                     // two dependent LDS round trips (~350 cycles each under the consumers' load), and one piece at a time is 8200
                     // cycles per item (`profiles/r03_bf16ws_stamps.txt`), nearly twice the consumers' k-loop.  (An LDS store between
