@@ -1,11 +1,11 @@
-"""GPU box: bf16 mode at 64 x 256x256 - producer/consumer kernels vs the round-2 kernel (PNP_BF16_NO_WS) vs the bf16 oracle."""
+"""GPU box: bf16 mode at 64 x 256x256 (or N H W from the command line) - producer/consumer kernels vs the round-2 kernel (PNP_BF16_NO_WS) vs the bf16 oracle."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dt4image_restoration_amd.engine import PnPEngine
 from dt4image_restoration_amd.weights import generate_unet_weights
 from dt4image_restoration_amd import synthetic
 from oracle import pnp_oracle as O
-n, h, w = 64, 256, 256
+n, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 256, 256)
 sdn = generate_unet_weights(0, "unit_gain")
 x = ((torch.from_numpy(synthetic.hash_uniform(9, 64256, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5)
 sigma = torch.linspace(3, 60, n) / 255.0
