@@ -25,6 +25,12 @@
 #include <cstdlib>
 // Diagnostic build (-DPNP_WS_STAMPS, `make stamps`; tools/ws_stamps.py): s_memtime of consumer wave 0 and producer wave 4 of one
 // workgroup at every hand-over, per launch.
+// Diagnostic build (-DPNP_WS_RACE_DBG, tools/race_dbg.py; round 5): the separable producers check every patch row they store -
+// a second evaluation from the same registers, the bytes that are in LDS, the row weights re-read - and record the first mismatches.
+#ifdef PNP_WS_RACE_DBG
+#define RACE_REC 32                       // 32-bit words per record
+__device__ unsigned g_race_dbg[4 + 256 * RACE_REC];   // [0] mismatching rows, [1] rows checked (low 32 bits), then 256 records
+#endif
 #ifdef PNP_WS_STAMPS
 __device__ unsigned long long g_ws_stamps[64 * 2 * 128];
 static int g_ws_slot = 0;
@@ -392,17 +398,21 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                         // are done once, in registers, and each row is then ONE vertical lerp of two of them - a third of the 4-tap form's
                         // instructions.  Needs the regular line structure of upsample_lines_regular() (pnp_create keeps other heights off this kernel).
                         //
-                        // The vertical lerp is written in non-packed instructions ON PURPOSE.  What hipcc makes of the plain expression - v_pk_mul_f32 /
-                        // v_pk_fma_f32 with op_sel swizzles, the destination pair overlapping the row-weight pair, two v_cvt_pk_bf16_f32, ds_write_b64, and
-                        // the next row's ds_read_b64 into the registers just stored - produced, in this kernel (a consumer wave issuing MFMAs on the same
-                        // SIMD), results that differed from pass to pass in one channel of a piece: 998 of 1000 passes, 0 of 600 with the four
-                        // lines below (and 0 in a stand-alone probe without MFMA traffic, exp/ds_write_hazard.hip).  Three bf16 separable variants
-                        // of this round died of it before it was pinned down.
+                        // The vertical lerp goes through lerp_np() (conv_staging.h): plain v_mul_f32 / v_fma_f32 that hipcc cannot re-pack.  What it
+                        // makes of the plain expression is v_pk_mul_f32 / v_pk_fma_f32 that broadcast the second row weight of the loaded {w0, w1}
+                        // pair with op_sel = 1 - the LOW result reads the HIGH register - and on MI355X that operand reads ZERO in lanes 48-63 about
+                        // once in 200 such instructions while the consumer wave of the SIMD runs bf16 MFMAs fed by buffer loads (round 5:
+                        // profiles/r05_race.md; stand-alone reproducer exp/pk_opsel_probe.hip; `-DPNP_WS_LERP_PACKED` rebuilds the faulty form:
+                        // ~2000 wrong patch values per denoiser pass, 1/3 to all passes differing).  Round 4 met this as "non-repeatable"
+                        // variants and kept the inline assembly without knowing why it helped.  The horizontal lerps below pack into forms whose
+                        // HIGH result reads the LOW register (op_sel_hi = 0), which the probe shows clean; tools/isa_audit.py (make audit, the
+                        // CPU test suite) fails if a low-reads-high packed operand appears in any kernel with bf16 MFMAs.
                         auto lerp1 = [](float wa, float a_, float wb, float b_) {
-                            float t, r;
-                            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(wa), "v"(a_));
-                            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(wb), "v"(b_), "v"(t));
-                            return r;
+#if defined(PNP_WS_LERP_PACKED)
+                            return wa * a_ + wb * b_;
+#else
+                            return lerp_np(wa, a_, wb, b_);
+#endif
                         };
                         constexpr int NG = (PH + 5) / 6;               // row groups of six (the last one may be short)
                         static_assert(3 * (NG - 1) + 3 < LH, "a group's four source lines are inside the parked region");
@@ -432,6 +442,40 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                                     const bf16x2 lo = __builtin_convertvector((f32x2){o.x, o.y}, bf16x2);
                                     const bf16x2 hi = __builtin_convertvector((f32x2){o.z, o.w}, bf16x2);
                                     if (rok) *reinterpret_cast<uint2*>(dst + i * (PW * CKP)) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+#ifdef PNP_WS_RACE_DBG
+                                    if (rok) {
+                                        // (1) the same expression once more from opaque copies of the same registers
+                                        float4 ha2 = ha, hb2 = hb; float2 rw2 = rw;
+                                        asm volatile("" : "+v"(ha2.x), "+v"(ha2.y), "+v"(ha2.z), "+v"(ha2.w), "+v"(hb2.x), "+v"(hb2.y), "+v"(hb2.z), "+v"(hb2.w), "+v"(rw2.x), "+v"(rw2.y));
+                                        const float4 o2 = make_float4(lerp1(rw2.x, ha2.x, rw2.y, hb2.x), lerp1(rw2.x, ha2.y, rw2.y, hb2.y), lerp1(rw2.x, ha2.z, rw2.y, hb2.z), lerp1(rw2.x, ha2.w, rw2.y, hb2.w));
+                                        const unsigned e0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o2.x, o2.y}, bf16x2));
+                                        const unsigned e1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){o2.z, o2.w}, bf16x2));
+                                        // (2) what LDS holds now (same wave, in order behind the store), (3) the row weights re-read
+                                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                        const u32x2 got_ = *reinterpret_cast<volatile u32x2*>(dst + i * (PW * CKP));
+                                        const u32x2 rw3_ = *reinterpret_cast<volatile u32x2*>(const_cast<float*>(&tb[4 * (6 * rg + i)]));
+                                        const uint2 got = make_uint2(got_.x, got_.y);
+                                        const float2 rw3 = make_float2(__uint_as_float(rw3_.x), __uint_as_float(rw3_.y));
+                                        const unsigned s0 = __builtin_bit_cast(unsigned, lo), s1 = __builtin_bit_cast(unsigned, hi);
+                                        const int kind = (got.x != s0 || got.y != s1 ? 1 : 0) | (e0 != s0 || e1 != s1 ? 2 : 0) |
+                                                         (__float_as_uint(rw3.x) != __float_as_uint(rw.x) || __float_as_uint(rw3.y) != __float_as_uint(rw.y) ? 4 : 0);
+                                        if (lane == 0) atomicAdd(&g_race_dbg[1], 1u);
+                                        if (kind) {
+                                            const unsigned slot = atomicAdd(&g_race_dbg[0], 1u);
+                                            if (slot < 256) {
+                                                unsigned* r = &g_race_dbg[4 + slot * RACE_REC];
+                                                r[0] = kind; r[1] = blockIdx.x; r[2] = (wid << 8) | lane; r[3] = (rd << 16) | (rg << 8) | i;
+                                                r[4] = __float_as_uint(rw.x); r[5] = __float_as_uint(rw.y);
+                                                r[6] = __float_as_uint(ha.x); r[7] = __float_as_uint(ha.y); r[8] = __float_as_uint(ha.z); r[9] = __float_as_uint(ha.w);
+                                                r[10] = __float_as_uint(hb.x); r[11] = __float_as_uint(hb.y); r[12] = __float_as_uint(hb.z); r[13] = __float_as_uint(hb.w);
+                                                r[14] = s0; r[15] = s1; r[16] = e0; r[17] = e1; r[18] = got.x; r[19] = got.y;
+                                                r[20] = __float_as_uint(rw3.x); r[21] = __float_as_uint(rw3.y); r[22] = (unsigned)__builtin_amdgcn_s_memtime(); r[23] = a.H;
+                                                r[24] = __float_as_uint(o.x); r[25] = __float_as_uint(o.y); r[26] = __float_as_uint(o.z); r[27] = __float_as_uint(o.w);
+                                                r[28] = __float_as_uint(o2.x); r[29] = __float_as_uint(o2.y); r[30] = __float_as_uint(o2.z); r[31] = __float_as_uint(o2.w);
+                                            }
+                                        }
+                                    }
+#endif
                                 }
                             }
                         }
@@ -471,7 +515,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             if (k0 + j < NIT && p0 + 32 * (k0 + j) < PH * PW)
-                                store_bf16(buf, k0 + j, f4lerp2(q[j][0], q[j][1], q[j][2], q[j][3], ct[j].z, ct[j].w, rt[j].z, rt[j].w));
+                                store_bf16(buf, k0 + j, f4lerp2<true>(q[j][0], q[j][1], q[j][2], q[j][3], ct[j].z, ct[j].w, rt[j].z, rt[j].w));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     return;
@@ -925,6 +969,10 @@ hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_
 
 }  // namespace pnp
 
+#ifdef PNP_WS_RACE_DBG
+extern "C" int pnp_debug_race_reset(void) { static unsigned z[4 + 256 * RACE_REC]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_race_dbg), z, sizeof(z)); }
+extern "C" int pnp_debug_race_read(unsigned* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_race_dbg), sizeof(unsigned) * (4 + 256 * RACE_REC)); }
+#endif
 #ifdef PNP_WS_STAMPS
 extern "C" int pnp_debug_ws_stamps_reset(void) { g_ws_slot = 0; return 0; }
 extern "C" int pnp_debug_ws_stamps_read(unsigned long long* dst) {

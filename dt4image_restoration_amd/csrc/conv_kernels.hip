@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
                 const float* l1 = &lowres[__float_as_int(rt.y) + part * 4];
                 const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
                 store_patch(py, px, part,
-                            f4lerp2(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
+                            f4lerp2<BF16 != 0>(*reinterpret_cast<const float4*>(l0 + c0), *reinterpret_cast<const float4*>(l0 + c1),
                                     *reinterpret_cast<const float4*>(l1 + c0), *reinterpret_cast<const float4*>(l1 + c1),
                                     ct.z, ct.w, rt.z, rt.w));
             }

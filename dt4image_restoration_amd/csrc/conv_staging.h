@@ -12,10 +12,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 f4max(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
+// Vector arithmetic that hipcc must NOT pack (MI355X, measured in round 5 - profiles/r05_race.md, exp/pk_opsel_probe.hip): a
+// v_pk_{mul,fma,add}_f32 whose LOW result reads the HIGH register of a source pair (op_sel bit = 1: hipcc's SLP vectoriser forms these
+// freely, e.g. to broadcast the second weight of a loaded {w0, w1} pair) reads ZERO for that operand in lanes 48-63, about once in 200
+// such instructions, while the other wave of the SIMD runs bf16 MFMAs fed by global loads.  f32 MFMAs (they hold the vector issue port) and
+// kernels without MFMAs do not trigger it.  Every kernel with bf16 MFMAs therefore does its interpolation arithmetic through these two
+// (plain v_mul_f32 / v_fma_f32 the compiler cannot re-pack), and tools/isa_audit.py fails the build if such an operand form appears in one.
+__device__ __forceinline__ float mul_np(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fma_np(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// w0 * a + w1 * b, evaluated as fma(w1, b, w0 * a)
+__device__ __forceinline__ float lerp_np(float w0, float a, float w1, float b) { return fma_np(w1, b, mul_np(w0, a)); }
+
+template <bool NP = false>
 __device__ __forceinline__ float4 f4lerp2(float4 p00, float4 p01, float4 p10, float4 p11, float wx0, float wx1,
                                           float wy0, float wy1) {
     // ATen upsample_bilinear2d: wy0*(wx0*p00 + wx1*p01) + wy1*(wx0*p10 + wx1*p11)
     float4 r;
+    if constexpr (NP) {                    // kernels with bf16 MFMAs (above)
+        r.x = lerp_np(wy0, lerp_np(wx0, p00.x, wx1, p01.x), wy1, lerp_np(wx0, p10.x, wx1, p11.x));
+        r.y = lerp_np(wy0, lerp_np(wx0, p00.y, wx1, p01.y), wy1, lerp_np(wx0, p10.y, wx1, p11.y));
+        r.z = lerp_np(wy0, lerp_np(wx0, p00.z, wx1, p01.z), wy1, lerp_np(wx0, p10.z, wx1, p11.z));
+        r.w = lerp_np(wy0, lerp_np(wx0, p00.w, wx1, p01.w), wy1, lerp_np(wx0, p10.w, wx1, p11.w));
+        return r;
+    }
     r.x = wy0 * (wx0 * p00.x + wx1 * p01.x) + wy1 * (wx0 * p10.x + wx1 * p11.x);
     r.y = wy0 * (wx0 * p00.y + wx1 * p01.y) + wy1 * (wx0 * p10.y + wx1 * p11.y);
     r.z = wy0 * (wx0 * p00.z + wx1 * p01.z) + wy1 * (wx0 * p10.z + wx1 * p11.z);
