@@ -387,14 +387,17 @@ def test_fused_first_and_last_layer_match_their_own_kernels(sd_np, monkeypatch):
 
 
 # ---- round 4: repeatability -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(32, 256, 256), (16, 512, 512), (6, 256, 128)])
 @pytest.mark.parametrize("mode", ["f32", "bf16", "bf16-direct-kernels", "bf16-one-term"])
-def test_denoiser_passes_are_bit_repeatable(sd_np, mode, monkeypatch):
-    """Two passes over the same input give the same bits on every kernel family at a chip-filling size (32 x 256 x 256): no
-    kernel depends on workgroup timing.  (Round 4 met two variants that passed every oracle tolerance and were not repeatable -
-    a separable upsample interpolation in the bf16 direct kernel's 4 x 2 tile and the same in the producer waves of
-    conv3x3_bf16ws_kernel; neither is in the tree, profiles/r04_ablation.md.)"""
+def test_denoiser_passes_are_bit_repeatable(sd_np, mode, size, monkeypatch):
+    """Passes over the same input give the same bits on every kernel family: at a chip-filling size, on the 16 x 512 x 512 plan BASELINE
+    configs[4] is timed on, and on a non-square size (tile rows and columns differ) - no kernel depends on workgroup timing.
+    Round 4 met variants that passed every oracle tolerance and were not repeatable, and shipped the separable producers of
+    conv3x3_bf16ws_kernel behind an inline-assembly workaround with the cause open.  Round 5 found it (profiles/r05_race.md): a packed-FP32
+    operand form hipcc emits reads zero in lanes 48-63 now and then beside bf16 MFMAs - an instruction-level fault, reproduced stand-alone;
+    the kernels keep off that form (conv_staging.h lerp_np) and tools/isa_audit.py checks the built library for it."""
     from dt4image_restoration_amd.engine import PnPEngine
-    n, h, w = 32, 256, 256
+    n, h, w = size
     if mode == "bf16-direct-kernels":
         monkeypatch.setenv("PNP_BF16_NO_WS", "1")
     if mode == "bf16-one-term":
@@ -404,7 +407,7 @@ def test_denoiser_passes_are_bit_repeatable(sd_np, mode, monkeypatch):
     x = ((torch.from_numpy(synthetic.hash_uniform(31, 7, n * h * w).reshape(n, 1, h, w)) + 1) * 0.5).cuda()
     sigma = (torch.linspace(4, 55, n) / 255.0).cuda()
     first = e.denoise(x, sigma).clone()
-    for _ in range(40):                                     # (a pass is ~5 ms; the race this caught in round 4 showed once in dozens of passes)
+    for _ in range(40):                                     # (a pass is ~5 ms; the faulty build differs in a third to all of its passes)
         assert torch.equal(e.denoise(x, sigma), first)
 
 

@@ -118,6 +118,26 @@ def test_host_side_under_asan_ubsan():
     assert "0 failures" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_no_low_reads_high_packed_ops_next_to_bf16_mfma():
+    """Round 5 (profiles/r05_race.md): on MI355X a v_pk_{mul,fma,add}_f32 operand whose LOW result reads the HIGH register of the pair
+    (op_sel = 1) reads zero in lanes 48-63 now and then while the SIMD's other wave runs bf16 MFMAs fed by loads; hipcc forms such operands from
+    plain scalar source.  The code objects inside the BUILT library must hold none in a kernel with non-f32 MFMAs (tools/isa_audit.py
+    disassembles them); the f32-MFMA and MFMA-free kernels may (measured safe: exp/pk_opsel_probe.hip)."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("no llvm-objdump / library")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), "--lib", _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 kernels flagged" in r.stdout and "conv3x3_bf16ws" not in r.stdout.replace("  ok", "")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_patch
+    # the detector itself: the forms the probe found faulty and the ones it found clean
+    assert isa_patch.parse_pk("\tv_pk_mul_f32 v[42:43], v[84:85], v[94:95] op_sel:[0,1]")["sel"] == [0, 1]
+    assert isa_patch.parse_pk("\tv_pk_fma_f32 v[80:81], v[116:117], v[80:81], v[118:119] op_sel:[0,1,0] op_sel_hi:[1,0,1]")["crossed_overlap"]
+    assert isa_patch.parse_pk("\tv_pk_fma_f32 v[96:97], v[72:73], v[78:79], v[42:43] op_sel_hi:[0,1,1]")["sel"] == [0, 0, 0]
+
+
 def test_unet_spec_counts():
     assert len(unet_spec.UNET_LAYERS) == 28 and len(unet_spec.STATE_DICT_KEYS) == 56
     assert unet_spec.N_PARAMS == 11_773_857

@@ -5,7 +5,8 @@ The fault (MI355X, ROCm 7.2): in a wave that shares its SIMD with a wave streami
 result reads the HIGH register of a source pair (op_sel bit = 1 for that source) sometimes sees ZERO for that operand in lanes 48-63.
 Same instruction stream with the operand copied into a straight pair first: clean (tools/isa_patch.py `uncross_lo`).
 
-    python tools/isa_audit.py [file.hip ...]        # default: every .hip under dt4image_restoration_amd/csrc
+    python tools/isa_audit.py --lib [libpnpadmm.so] # the code objects inside the BUILT library (default: the in-tree one) - seconds
+    python tools/isa_audit.py [file.hip ...]        # compile to ISA first (default: every .hip under dt4image_restoration_amd/csrc) - minutes
     python tools/isa_audit.py --asm file.s
 
 Per kernel: packed-f32 ops, those with an op_sel = 1 source ("low reads high"), and the matrix instructions of the kernel.  Exit code 1 if a
@@ -30,6 +31,48 @@ def asm_of(src, extra=()):
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
                     "-S", "--cuda-device-only", src, "-o", out, *extra], check=True, stderr=subprocess.DEVNULL)
     return out
+
+
+def code_objects(lib):
+    """the gfx950 code objects embedded in a host library: every __CLANG_OFFLOAD_BUNDLE__ in it (one per translation unit)"""
+    blob = open(lib, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, at = [], blob.find(magic)
+    while at >= 0:
+        import struct
+        n = struct.unpack_from("<Q", blob, at + len(magic))[0]
+        q = at + len(magic) + 8
+        for _ in range(n):
+            off, size, idlen = struct.unpack_from("<QQQ", blob, q)
+            ident = blob[q + 24:q + 24 + idlen].decode()
+            q += 24 + idlen
+            if "amdgcn" in ident and size:
+                out.append(blob[at + off:at + off + size])
+        at = blob.find(magic, at + len(magic))
+    return out
+
+
+def disassemble(lib):
+    """llvm-objdump of every embedded code object, rewritten to the `name:` / instruction / `.Lfunc_end` shape audit_asm() reads"""
+    paths = []
+    for i, co in enumerate(code_objects(lib)):
+        f = "/tmp/_isa_audit_co%d.o" % i
+        open(f, "wb").write(co)
+        txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", f], check=True, capture_output=True, text=True).stdout
+        lines = []
+        for l in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+            if m:
+                if lines:
+                    lines.append(".Lfunc_end")
+                lines.append(m.group(1) + ":")
+            else:
+                lines.append(l.split("//")[0].rstrip())
+        lines.append(".Lfunc_end")
+        out = "/tmp/_isa_audit_co%d.s" % i
+        open(out, "w").write("\n".join(lines))
+        paths.append(out)
+    return paths
 
 
 def audit_asm(path, verbose=True):
@@ -66,6 +109,10 @@ def main():
     args = sys.argv[1:]
     if args and args[0] == "--asm":
         sys.exit(1 if audit_asm(args[1])[0] else 0)
+    if args and args[0] == "--lib":
+        lib = args[1] if len(args) > 1 else os.path.join(CSRC, "libpnpadmm.so")
+        bad = sum(audit_asm(f)[0] for f in disassemble(lib))
+        sys.exit(1 if bad else 0)
     srcs = args or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     bad = 0
     for s in srcs:
