@@ -22,7 +22,6 @@
 // store the tiles as well - OFFLOAD below - and the consumers hold the layer's weights in registers - HOLDHI.)
 #include "pnp_internal.h"
 #include "conv_staging.h"
-#include <cstdlib>
 // Diagnostic build (-DPNP_WS_STAMPS, `make stamps`; tools/ws_stamps.py): s_memtime of consumer wave 0 and producer wave 4 of one
 // workgroup at every hand-over, per launch.
 // Diagnostic build (-DPNP_WS_RACE_DBG, tools/race_dbg.py; round 5): the separable producers check every patch row they store -
@@ -351,12 +350,22 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
         };
         auto issue = [&](int c, RawSet& raw) {
             if constexpr (UP2) {
-                if (c >= nskip) {                              // the low-res region of an upsampled chunk
-                    const int sol = (c - nskip) * CK * 4;
+                // ONE load sequence for both kinds of chunk - the skip tensor's pieces or the low-res region of an upsampled chunk - with the
+                // descriptor, the scalar offset and each piece's byte offset selected by the (wave-uniform) kind; a piece the kind does not have
+                // carries the out-of-range offset and costs an issue slot, no memory traffic.  (Rounds 3-4 had one loop per kind in the two arms
+                // of a branch: hipcc sank the arms' last stores into a store through a PHI of the two raw-set elements' addresses, which kept
+                // four float4 of the raw sets in scratch memory - a scratch_store right behind the loads, i.e. `s_waitcnt vmcnt(0)` at ISSUE time
+                // in every UPCAT instantiation: the producers waited for the loads they had just sent out two items ahead, 48-80 B of
+                // scratch, `profiles/r05_ablation.md`.)
+                const bool up = c >= nskip;
+                const int so = up ? (c - nskip) * CK * 4 : c * CK * ESZ;
+                const __amdgpu_buffer_rsrc_t rs = up ? rsrcL : rsrc;
 #pragma unroll
-                    for (int k = 0; k < NITL; ++k) raw[k][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, goffL[k], sol, 0));
-                    return;
+                for (int k = 0; k < NR; ++k) {
+                    const unsigned o = up ? (k < NITL ? goffL[k < NITL ? k : 0] : 0x80000000u) : (k < NITS ? goff[k < NITS ? k : 0] : 0x80000000u);
+                    raw[k][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, so, 0));
                 }
+                return;
             }
             const int so = c * CK * ESZ;
 #pragma unroll
@@ -886,6 +895,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);             // (the next M-block's LDS writes follow these reads in program order)
             }
         } else {
+            // (UPCAT instantiations, f32 dst: only the PNP_BF16_F32_ACTS ablation comes here.)  The 64 per-register scalar offsets below are
+            // loop invariants: hipcc hoisted them out of the tile loop and spilled 160 SGPRs to keep them - in every UPCAT instantiation,
+            // whether this path runs or not.  The two factors pass through an opaque asm inside the loop, so each offset is two scalar
+            // multiplies at its store.
+            int rowb = a.W * a.Cout * 4, pixb = a.Cout * 4;
+            asm volatile("" : "+s"(rowb), "+s"(pixb));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = (cbt * (WN * NT) + wn * NT + nt) * 32 + li;
@@ -896,7 +911,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int qc = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2);   // tile pixel index, lane-independent part
                         const int gy = ty0 + qc / TW, gx = tx0 + qc % TW + 4 * hh;
-                        const int soff = __builtin_amdgcn_readfirstlane(((qc / TW) * a.W + qc % TW) * a.Cout * 4);
+                        const int soff = (qc / TW) * rowb + (qc % TW) * pixb;
                         const float v = fmaxf(acc[mt][nt][r], kLeaky * acc[mt][nt][r]);
                         if (gy < a.H && gx < a.W) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, obase, soff, 0);
                     }
@@ -922,10 +937,9 @@ static hipError_t launch_k(const ConvArgs& a, unsigned grid, hipStream_t s) {
 }
 
 template <int TW, int WM, int WN, int MT, int NT, int SRC>
-static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
-    if constexpr (NT == 1 && SRC == SRC_PLAIN) {           // 32 -> 32 layers: the hi fragments stay in registers (HOLDHI)
-        static const bool off = getenv("PNP_BF16_NO_HOLDHI") != nullptr;   // (ablation switch, process-wide)
-        if (a.bf16 == 2 && a.Cin == 32 && a.Cout == 32 && !off)
+static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s, bool holdhi) {
+    if constexpr (NT == 1 && SRC == SRC_PLAIN) {           // 32 -> 32 layers: the hi fragments stay in registers (HOLDHI; the handle's plan decides)
+        if (a.bf16 == 2 && a.Cin == 32 && a.Cout == 32 && holdhi)
             return (a.act16 & 1) ? launch_k<TW, WM, WN, MT, NT, SRC, true, 2, true>(a, grid, s) : launch_k<TW, WM, WN, MT, NT, SRC, false, 2, true>(a, grid, s);
     }
     if (a.bf16 == 2)
@@ -934,12 +948,12 @@ static hipError_t launch_one(const ConvArgs& a, unsigned grid, hipStream_t s) {
 }
 
 template <int TW, int WM, int WN, int MT, int NT>
-static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hipStream_t s) {
-    if (src_mode == SRC_PLAIN) return launch_one<TW, WM, WN, MT, NT, SRC_PLAIN>(a, grid, s);
+static hipError_t launch_src(const ConvArgs& a, int src_mode, unsigned grid, hipStream_t s, bool holdhi) {
+    if (src_mode == SRC_PLAIN) return launch_one<TW, WM, WN, MT, NT, SRC_PLAIN>(a, grid, s, holdhi);
     if constexpr (WN == 2) {
-        if (src_mode == SRC_POOL) return launch_one<TW, WM, WN, MT, NT, SRC_POOL>(a, grid, s);
+        if (src_mode == SRC_POOL) return launch_one<TW, WM, WN, MT, NT, SRC_POOL>(a, grid, s, holdhi);
     }
-    if (src_mode == SRC_UPCAT && a.Cskip % 32 == 0 && a.Cskip >= 32 && a.Cin - a.Cskip >= 32) return launch_one<TW, WM, WN, MT, NT, SRC_UPCAT>(a, grid, s);
+    if (src_mode == SRC_UPCAT && a.Cskip % 32 == 0 && a.Cskip >= 32 && a.Cin - a.Cskip >= 32) return launch_one<TW, WM, WN, MT, NT, SRC_UPCAT>(a, grid, s, holdhi);
     return hipErrorInvalidValue;
 }
 
@@ -956,13 +970,13 @@ hipError_t launch_conv3x3_bf16ws(const ConvArgs& a0, const ConvPlan& p, int src_
     const long total = (long)p.tiles_x * p.tiles_y * a.N * (a.Cout / p.bn);
     const unsigned grid = (unsigned)(total < 256 ? total : 256);     // persistent: one workgroup (8 waves) per CU
     if (p.nt == 1) {
-        if (p.tw == 32 && p.mt == 2 && p.wm == 4) return launch_src<32, 4, 1, 2, 1>(a, src_mode, grid, s);
+        if (p.tw == 32 && p.mt == 2 && p.wm == 4) return launch_src<32, 4, 1, 2, 1>(a, src_mode, grid, s, p.holdhi != 0);
     } else if (p.wn == 2) {
-        if (p.tw == 32) return launch_src<32, 2, 2, 4, 2>(a, src_mode, grid, s);
-        if (p.tw == 16) return launch_src<16, 2, 2, 4, 2>(a, src_mode, grid, s);
+        if (p.tw == 32) return launch_src<32, 2, 2, 4, 2>(a, src_mode, grid, s, p.holdhi != 0);
+        if (p.tw == 16) return launch_src<16, 2, 2, 4, 2>(a, src_mode, grid, s, p.holdhi != 0);
     } else {
-        if (p.tw == 32) return launch_src<32, 4, 1, 4, 2>(a, src_mode, grid, s);
-        if (p.tw == 16) return launch_src<16, 4, 1, 4, 2>(a, src_mode, grid, s);
+        if (p.tw == 32) return launch_src<32, 4, 1, 4, 2>(a, src_mode, grid, s, p.holdhi != 0);
+        if (p.tw == 16) return launch_src<16, 4, 1, 4, 2>(a, src_mode, grid, s, p.holdhi != 0);
     }
     return hipErrorInvalidValue;
 }

@@ -340,7 +340,8 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
             e->cplan[li] = conv3x3_plan(cfg->n, lh, lw, L.cin, L.cout, bf16, src_mode, ws_ok);
             // up4.conv-2 (fused last layer): on the producer / consumer kernel only in the two-term mode, where its producers evaluate the last
             // layer (OFFLOAD); the one-term form of that tile measured slower than conv_kernels.hip (conv3x3_plan)
-            if (li == 26 && e->cplan[li].nt == 1 && (e->bf16_terms != 2 || getenv("PNP_BF16_NO_HOLDHI") != nullptr)) e->cplan[li].ws = 0;
+            e->cplan[li].holdhi = e->tune.bf16_no_holdhi ? 0 : 1;
+            if (li == 26 && e->cplan[li].nt == 1 && (e->bf16_terms != 2 || e->tune.bf16_no_holdhi)) e->cplan[li].ws = 0;
             e->wino[li] = e->wplan[li].use && !bf16;
             if (e->wino[li] && e->wplan[li].algo == 4) continue;          // (per-slice descriptors)
             if (!conv3x3_tensor_fits(cfg->n, lh, lw, L.cin, L.cout))

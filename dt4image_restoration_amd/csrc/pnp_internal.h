@@ -25,6 +25,7 @@ struct Tuning {
                                   // 64-channel-block layer on 16-tile M-blocks
     bool bf16_no_ws = false;      // PNP_BF16_NO_WS (ablation): bf16 mode without the producer / consumer kernel (the round-2 kernel everywhere)
     bool bf16_f32_acts = false;   // PNP_BF16_F32_ACTS (ablation): bf16 mode keeps every activation in f32, as rounds 1-2 did
+    bool bf16_no_holdhi = false;  // PNP_BF16_NO_HOLDHI (ablation): the 32 -> 32 layers of the bf16 mode stream their weights instead of holding them
     bool bf16_w1 = false;         // PNP_BF16_W1 (ablation): bf16 mode with ONE bf16 term per weight (the round-3 arithmetic: 0.015 dB of
                                   // PSNR drift against the f32 reference over configs[4]'s 50 iterations) instead of hi + lo
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
@@ -96,6 +97,7 @@ struct ConvPlan {
     int ck;            // input channels per staged chunk (16 or 32)
     int splitk;        // K ranges (of whole chunks), one workgroup each; > 1 only on small problems
     int ws;            // bf16 mode: the producer / consumer kernel (conv_bf16_kernels.hip) runs this layer; ck = 32
+    int holdhi = 1;    // ws, 32 -> 32 layers under two-term weights: both weight fragments of every k-step held in registers (Tuning.bf16_no_holdhi)
     int tiles_x, tiles_y;
 };
 ConvPlan conv3x3_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false, int src_mode = SRC_PLAIN, bool allow_ws = true);

@@ -511,6 +511,35 @@ def test_config4_bf16_53_iterations_within_tolerance_of_reference(denoiser, gold
     assert d.max() < 0.005                                  # oracle (tools/bf16_drift.py): 0.002-0.003 with two-term weights
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_config4_timed_16_slice_plan_matches_reference(denoiser, golden_dir, bf16):
+    """The plan bench.py TIMES for BASELINE configs[4] (its `config4` leg and `--size 512 --batch 16 --accel 8 --steps 50 --warmup 3`): 16
+    slices of 512x512 - other tile plans and launch grids than the 2-slice engines of the tests above - stepped over all 53 iterations of
+    bench.py's parameter table, slices 0-1 against the reference's own trajectory (g8_config4.npz) at EVERY iteration; f32 and the bf16
+    mode (north_star's +-0.01 dB; measured ~1e-5 / 0.0013)."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    g = np.load(os.path.join(golden_dir, "g8_config4.npz"))
+    n, iters = 16, g["psnr"].shape[1]
+    mu_tab, sig_tab = synthetic.param_table(n, iters, seed=77)
+    assert np.array_equal(mu_tab[:2], g["mu_tab"]) and np.array_equal(sig_tab[:2], g["sig_tab"])   # the fixture's table is this table's head
+    data = synthetic.make_problem(n, 512, 512, accel=8.0, sigma_n=10.0 / 255.0, seed=1234)
+    e = PnPEngine(n, 512, 512, bf16_convs=bf16)
+    e.load_weights(denoiser.weights)
+    gt = torch.from_numpy(data["gt"]).cuda()
+    x, z, u = e.reset(torch.view_as_complex(torch.from_numpy(data["x0"])).cuda(),
+                      torch.view_as_complex(torch.from_numpy(data["y0"])).cuda(), torch.from_numpy(data["mask"]).cuda())
+    mu, sg = torch.from_numpy(mu_tab).cuda(), torch.from_numpy(sig_tab).cuda()
+    hist = []
+    for t in range(iters):
+        e.step(x, z, u, mu[:, t].contiguous(), sg[:, t].contiguous())
+        hist.append(e.psnr(x, gt)[:2])
+    d = np.abs(torch.stack(hist, dim=1).cpu().numpy() - g["psnr"])
+    print("16-slice plan,", "bf16" if bf16 else "f32", "|dPSNR| vs reference at it 1, 10, 30, 50, 53:", d[:, [0, 9, 29, 49, 52]].max(axis=0), "max", d.max())
+    assert d.max() < (0.005 if bf16 else 1e-3), d.max(axis=0)
+    if not bf16:
+        np.testing.assert_allclose(x[0, 0].cpu().numpy(), g["x_final_slice0"], rtol=0, atol=1e-4)
+
+
 def test_config4_bf16_one_term_weights_drift_is_what_the_oracle_says(denoiser, golden_dir, monkeypatch):
     """PNP_BF16_W1 (ablation): one bf16 term per weight, the round-3 arithmetic.  The engine follows the oracle's one-term mode
     (first iterations, same rounding points) and its offset to the reference after 53 iterations is the drift the two-term
