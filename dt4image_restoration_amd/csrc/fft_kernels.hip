@@ -266,6 +266,109 @@ __device__ __forceinline__ void fft256_radix16_inplace(float2* buf, const float2
     __syncthreads();
 }
 
+// ---- 512-point lines as THREE radix-8 passes with the 8-point transforms in registers (round 5; BASELINE configs[4] is 512 x 512: its
+// passes were the generic radix-4 x 4 + radix-2 ones, five LDS round trips per transform and 0.38-0.44 of their LDS cycles in bank
+// conflicts, profiles/r04_pmc_current_16x512x512_f32.md) ------------------------------------------------------------------------------
+// In place in one buffer; element i of a line lives at i + (i >> 3) (one pad element per 8).  A butterfly b (0..63) of a Stockham pass
+// reads positions b + 64 m and writes 8 b + q (Ns = 1), 64 (b >> 3) + (b & 7) + 8 q (Ns = 8), b + 64 q (Ns = 64); under the skew these
+// are sk(b) + 72 m, 9 b + q, 72 (b >> 3) + (b & 7) + 9 q, sk(b) + 72 q: consecutive lanes b stay on distinct banks in all of them.
+// Lines SK512_LS elements apart.
+static constexpr int SK512_LS = 576;   // (8 lines + the twiddle table = 40 KiB: four workgroups per CU)
+__device__ __forceinline__ int sk512(int i) { return i + (i >> 3); }
+
+// v[0..7] -> its 8-point DFT, result X[q] in v[4 (q & 1) + (q >> 1)] (one radix-2 stage, constant twiddles w8^k, two radix-4 stages)
+template <bool INV>
+__device__ __forceinline__ void dft8_inplace(float2* v) {
+    constexpr float R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float2 t = v[k]; v[k] = cadd(t, v[k + 4]); v[k + 4] = csub(t, v[k + 4]); }
+    // w8^k = (cos, -sin)(2 pi k / 8) forward, conjugate inverse
+    v[5] = cmul(v[5], make_float2(R2, INV ? R2 : -R2));
+    v[6] = INV ? make_float2(-v[6].y, v[6].x) : make_float2(v[6].y, -v[6].x);
+    v[7] = cmul(v[7], make_float2(-R2, INV ? R2 : -R2));
+    dft4_inplace<INV>(v[0], v[1], v[2], v[3]);             // X[0], X[2], X[4], X[6]
+    dft4_inplace<INV>(v[4], v[5], v[6], v[7]);             // X[1], X[3], X[5], X[7]
+}
+
+// LINES lines of 512 points, 256 threads, TPL threads per line (LINES * TPL <= 256): thread (line, j) owns the radix-8 butterflies
+// j, j + TPL, ... of its line in every pass (64 / TPL of them: two with 8 lines per workgroup, one with 4).
+template <bool INV, int LINES, int TPL>
+__device__ __forceinline__ void fft512_radix8_inplace(float2* buf, const float2* __restrict__ tw) {
+    static_assert((TPL == 32 || TPL == 64) && LINES * TPL <= 256, "threads per line");
+    constexpr int NB = 64 / TPL;
+    const int tid = threadIdx.x, line = tid / TPL, j = tid % TPL;
+    const bool on = line < LINES;
+    float2* const base = buf + line * SK512_LS;
+    float2 v[NB][8];
+    auto xq = [](int q) { return 4 * (q & 1) + (q >> 1); };  // where dft8_inplace leaves X[q]
+    // pass 1 (Ns = 1): no twiddles; X[q] -> position 8 b + q
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[h][m] = base[sk512(j + TPL * h) + 72 * m];
+    }
+    __syncthreads();                                       // in place: every read of the pass before any write
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            dft8_inplace<INV>(v[h]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) base[9 * (j + TPL * h) + q] = v[h][xq(q)];
+        }
+    }
+    __syncthreads();
+    // pass 2 (Ns = 8, k = b & 7): x[m] *= w64^(m k); X[q] -> position 64 (b >> 3) + k + 8 q
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                v[h][m] = base[sk512(j + TPL * h) + 72 * m];
+                if (m > 0) {
+                    float2 w = tw[8 * m * (j & 7)];
+                    if (INV) w.y = -w.y;
+                    v[h][m] = cmul(v[h][m], w);
+                }
+            }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            dft8_inplace<INV>(v[h]);
+            const int b = j + TPL * h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) base[72 * (b >> 3) + (b & 7) + 9 * q] = v[h][xq(q)];
+        }
+    }
+    __syncthreads();
+    // pass 3 (Ns = 64, k = b): x[m] *= w512^(m b); X[q] -> position b + 64 q
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                v[h][m] = base[sk512(j + TPL * h) + 72 * m];
+                if (m > 0) {
+                    float2 w = tw[m * (j + TPL * h)];
+                    if (INV) w.y = -w.y;
+                    v[h][m] = cmul(v[h][m], w);
+                }
+            }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            dft8_inplace<INV>(v[h]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) base[sk512(j + TPL * h) + 72 * q] = v[h][xq(q)];
+        }
+    }
+    __syncthreads();
+}
+
 static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in the row passes
 
 // MODE 0 generic (in -> out, index shifts), 1 ADMM forward (x + u -> work), 2 ADMM inverse (work -> z, u)
@@ -279,16 +382,21 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
                                                        const float2* __restrict__ twg, const float* __restrict__ tact,
                                                        int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    static_assert(!R16 || (LC == 256 && MODE != 0), "radix-16 rows: the 256-point ADMM passes");
-    constexpr int RE = R16 ? 16 * 256 : ROW_ELEMS;         // elements per workgroup (R16: 16 rows, so that all 256 threads own a butterfly)
-    auto slot = [&](int e) { return R16 ? (e >> 8) * SK256_LS + sk256(e & 255) : e; };
+    static_assert(!R16 || ((LC == 256 || LC == 512) && MODE != 0), "register-resident passes: the 256- / 512-point ADMM passes");
+    constexpr int RE = (R16 && LC == 256) ? 4096 : ROW_ELEMS;   // elements per workgroup (R16: 16 rows of 256 / 4 rows of 512 - every thread owns one butterfly per pass)
+    constexpr int RLS = LC == 512 ? SK512_LS : SK256_LS;   // (R16) skewed line stride
+    auto slot = [&](int e) { return !R16 ? e : (LC == 512 ? (e >> 9) * SK512_LS + sk512(e & 511) : (e >> 8) * SK256_LS + sk256(e & 255)); };
     float2* buf0 = smem;
     float2* buf1 = smem + (R16 ? 0 : rpb * W);
-    float2* tw = smem + (R16 ? (RE / 256) * SK256_LS : 2 * rpb * W);
+    float2* tw = smem + (R16 ? (RE / (LC > 0 ? LC : 1)) * RLS : 2 * rpb * W);
     const int blocks_per_img = H / rpb;
     const int n = blockIdx.x / blocks_per_img;
     const int y0 = (blockIdx.x % blocks_per_img) * rpb;
     if (MODE != 0 && tact != nullptr && tact[n] > 0.5f) return;
+    if (MODE != 0 && shift_out > 0) {                      // (experiment, PNP_FFT_STAGGER: start phases of the workgroups that share a CU)
+        const int ph = ((int)blockIdx.x >> 8) & 3;
+        for (int i = 0; i < ph * shift_out; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     const size_t base = ((size_t)n * H + y0) * W;
     const int tot = rpb * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) tw[i] = twg[i];
@@ -316,7 +424,11 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     __syncthreads();
     const bool inv = (MODE == 2) || (MODE == 0 && inverse);
     float2* res;
-    if constexpr (R16) {                                   // W == 256, 16 rows per workgroup (checked by the launcher)
+    if constexpr (R16 && LC == 512) {                      // W == 512, 4 rows per workgroup (checked by the launcher)
+        if constexpr (MODE == 2) fft512_radix8_inplace<true, 4, 64>(buf0, tw);
+        else fft512_radix8_inplace<false, 4, 64>(buf0, tw);
+        res = buf0;
+    } else if constexpr (R16) {                            // W == 256, 16 rows per workgroup (checked by the launcher)
         if constexpr (MODE == 2) fft256_radix16_inplace<true, RE / 256>(buf0, tw);
         else fft256_radix16_inplace<false, RE / 256>(buf0, tw);
         res = buf0;
@@ -366,14 +478,25 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
                                                        int inverse, int shift_in, int shift_out) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr bool R16 = MODE == 1 && LC == 256;           // 256-point columns of the ADMM pass: radix-16 passes, skewed lines
-    const int lstr = R16 ? SK256_LS : H + 1;
+    constexpr bool R8 = MODE == 1 && LC == 512;            // 512-point columns: radix-8 passes, skewed lines
+    const int lstr = R16 ? SK256_LS : (R8 ? SK512_LS : H + 1);
     float2* buf0 = smem;
     float2* buf1 = smem + cw * lstr;
     float2* tw = smem + ((MODE == 1 && LC > 0) ? 1 : 2) * cw * lstr;   // the unrolled ADMM variant works in place in buf0
     const int strips = W / cw;
-    const int n = blockIdx.x / strips;
-    const int x0 = (blockIdx.x % strips) * cw;
+    // Workgroups b, b + 8, b + 16, ... share an XCD (and its L2) and are dispatched back to back: each XCD walks a CONTIGUOUS range of
+    // (slice, strip) pairs, so the two 8-column strips that share every 128-byte line of a 512-point slice (and of its y0 / mask) run
+    // side by side on ONE L2 - the line comes from HBM once and its two half-line stores merge before they leave (round 5: the strips of a
+    // line pair used to sit on different XCDs, 2.6 x the algorithmic bytes moved at 512 x 512, profiles/r04_pmc_current_16x512x512_f32.md)
+    int vb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) vb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int n = vb / strips;
+    const int x0 = (vb % strips) * cw;
     if (MODE == 1 && tact != nullptr && tact[n] > 0.5f) return;
+    if (MODE == 1 && shift_out > 0) {
+        const int ph = ((int)blockIdx.x >> 8) & 3;
+        for (int i = 0; i < ph * shift_out; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     float2* img = data + (size_t)n * H * W;
     const int tot = cw * H;
     for (int i = threadIdx.x; i < H; i += blockDim.x) tw[i] = twg[i];
@@ -389,7 +512,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int e = e0 + k * 256;
-            if (e < tot) buf0[(e & (cw - 1)) * lstr + (R16 ? sk256(e >> lcw) : ((e >> lcw) ^ shift_in))] = v[k];
+            if (e < tot) buf0[(e & (cw - 1)) * lstr + (R16 ? sk256(e >> lcw) : (R8 ? sk512(e >> lcw) : ((e >> lcw) ^ shift_in)))] = v[k];
         }
     }
     __syncthreads();
@@ -405,7 +528,8 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
     } else if constexpr (LC > 0) {
         // H == LC, cw == CWC (checked by the launcher): the k-space constants of this strip are fetched BEFORE the forward
         // transform and sit in registers under it; all passes unrolled.
-        constexpr int CWC = LC <= 256 ? 16 : (LC <= 512 ? 8 : 4), LS = R16 ? SK256_LS : LC + 1, PER = CWC * LC / 256;
+        constexpr int CWC = LC <= 256 ? 16 : (LC <= 512 ? 8 : 4), LS = R16 ? SK256_LS : (R8 ? SK512_LS : LC + 1), PER = CWC * LC / 256;
+        auto rpos = [](int r) { return R16 ? sk256(r) : (R8 ? sk512(r) : r); };
         const float m = mu[n];
         const float inv1m = 1.f + m;
         const float2* y0n = y0s + (size_t)n * H * W;
@@ -420,28 +544,30 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
             yy[k] = y0n[g];
         }
         if constexpr (R16) fft256_radix16_inplace<false, CWC>(buf0, tw);
+        else if constexpr (R8) fft512_radix8_inplace<false, CWC, 32>(buf0, tw);
         else fft_lines_inplace<false, LC, CWC, LS>(buf0, tw);
         float2* const res = buf0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = threadIdx.x + k * 256;
             const int r = e / CWC, c = e % CWC;
-            float2 v = res[c * LS + (R16 ? sk256(r) : r)];
+            float2 v = res[c * LS + rpos(r)];
             v.x *= sc; v.y *= sc;                           // now the orthonormal FFT2 of x + u
             if (mm[k]) {                                    // sampled k-space bin: closed-form solve
                 v.x = (m * v.x + yy[k].x) / inv1m;
                 v.y = (m * v.y + yy[k].y) / inv1m;
             }
-            res[c * LS + (R16 ? sk256(r) : r)] = v;
+            res[c * LS + rpos(r)] = v;
         }
         __syncthreads();
         if constexpr (R16) fft256_radix16_inplace<true, CWC>(res, tw);
+        else if constexpr (R8) fft512_radix8_inplace<true, CWC, 32>(res, tw);
         else fft_lines_inplace<true, LC, CWC, LS>(res, tw);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = threadIdx.x + k * 256;
             const int r = e / CWC, c = e % CWC;
-            float2 v = res[c * LS + (R16 ? sk256(r) : r)];
+            float2 v = res[c * LS + rpos(r)];
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
         }
@@ -717,16 +843,25 @@ hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, in
     return hipGetLastError();
 }
 // 256-point rows: the radix-16 variant (16 rows per workgroup); PNP_FFT_ROWS_R4 (experiments) keeps the radix-4 passes
+static int fft_stagger() {
+    static const int v = getenv("PNP_FFT_STAGGER") ? atoi(getenv("PNP_FFT_STAGGER")) : 0;
+    return v;
+}
 static bool rows_r16(int H, int W) {
     static const bool off = getenv("PNP_FFT_ROWS_R4") != nullptr;
-    return !off && W == 256 && H % 16 == 0;
+    return !off && ((W == 256 && H % 16 == 0) || (W == 512 && H % 4 == 0));
 }
+
 
 hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* work, const float2* tw, const float* tact,
                                     int N, int H, int W, hipStream_t s) {
     if (rows_r16(H, W)) {
-        hipLaunchKernelGGL((fft_rows_kernel<1, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
-                           nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 16, 0, 0, 0);
+        if (W == 512)
+            hipLaunchKernelGGL((fft_rows_kernel<1, 512, true>), dim3(N * (H / 4)), dim3(256), (size_t)(4 * SK512_LS + W) * sizeof(float2), s,
+                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 4, 0, 0, fft_stagger());
+        else
+            hipLaunchKernelGGL((fft_rows_kernel<1, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
+                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 16, 0, 0, fft_stagger());
         return hipGetLastError();
     }
     const int rpb = rows_per_block(H, W);
@@ -749,9 +884,9 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
     if (hipError_t e = raise_lds_cap()) return e;
 #define PNP_COLS_PROX(LC_)                                                                                    \
     hipLaunchKernelGGL((fft_cols_kernel<1, LC_>), dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu, \
-                       tact, H, W, cw, 0, 0, 0)
+                       tact, H, W, cw, 0, 0, fft_stagger())
     const bool ct = cw == (H <= 256 ? 16 : (H <= 512 ? 8 : 4)) && (H == 128 || H == 256 || H == 512);   // W >= one full strip
-    if (ct) lds = (size_t)(cw * (H == 256 ? SK256_LS : H + 1) + H) * sizeof(float2);      // in place: one strip buffer
+    if (ct) lds = (size_t)(cw * (H == 256 ? SK256_LS : (H == 512 ? SK512_LS : H + 1)) + H) * sizeof(float2);      // in place: one strip buffer
     if (ct && H == 128) PNP_COLS_PROX(128);
     else if (ct && H == 256) PNP_COLS_PROX(256);
     else if (ct && H == 512) PNP_COLS_PROX(512);
@@ -762,8 +897,12 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
 hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* z, float2* u, const float2* tw,
                                     const float* tact, int N, int H, int W, hipStream_t s) {
     if (rows_r16(H, W)) {
-        hipLaunchKernelGGL((fft_rows_kernel<2, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
-                           work, z, x, u, tw, tact, H, W, 16, 1, 0, 0);
+        if (W == 512)
+            hipLaunchKernelGGL((fft_rows_kernel<2, 512, true>), dim3(N * (H / 4)), dim3(256), (size_t)(4 * SK512_LS + W) * sizeof(float2), s,
+                               work, z, x, u, tw, tact, H, W, 4, 1, 0, fft_stagger());
+        else
+            hipLaunchKernelGGL((fft_rows_kernel<2, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
+                               work, z, x, u, tw, tact, H, W, 16, 1, 0, fft_stagger());
         return hipGetLastError();
     }
     const int rpb = rows_per_block(H, W);

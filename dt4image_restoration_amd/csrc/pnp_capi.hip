@@ -168,6 +168,25 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
         HIP_TRY(launch_conv_first(ximg, z, u, sigma, tact, e->d_wpack[0], e->d_bias[0], e->lv[0].p, N, H, W, s, e->act16));
     }
     const bool per_layer = (e->cfg.flags & PNP_FLAG_PROFILE_LAYERS) != 0;
+#ifdef PNP_DIAG
+    static hipStream_t diag_pool[8];
+    static hipEvent_t diag_fork, diag_join[8];
+    static int diag_made = 0;
+    const int diag_k = getenv("PNP_DIAG_STREAMS") ? std::min(8, std::max(1, atoi(getenv("PNP_DIAG_STREAMS")))) : 1;
+    if (diag_k > 1) {
+        if (!diag_made) {
+            for (int i = 0; i < 8; ++i) { HIP_TRY(hipStreamCreateWithFlags(&diag_pool[i], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&diag_join[i], hipEventDisableTiming)); }
+            HIP_TRY(hipEventCreateWithFlags(&diag_fork, hipEventDisableTiming));
+            diag_made = 1;
+        }
+        HIP_TRY(hipEventRecord(diag_fork, s));
+        for (int i = 0; i < diag_k; ++i) HIP_TRY(hipStreamWaitEvent(diag_pool[i], diag_fork, 0));
+    }
+    struct DiagJoin {
+        hipStream_t s; int k; hipStream_t* pool; hipEvent_t* ev;
+        ~DiagJoin() { if (k > 1) for (int i = 0; i < k; ++i) { (void)hipEventRecord(ev[i], pool[i]); (void)hipStreamWaitEvent(s, ev[i], 0); } }
+    } diag_joiner{s, diag_k, diag_pool, diag_join};
+#endif
     Prof run(e, s, 0, -1, !per_layer, true);              // one event pair around the whole conv3x3 run
     int run_launches = 0;
     auto conv = [&](int li, const float* src0, const float* src1, float* dst, int lvl, float* pooled = nullptr,
@@ -196,9 +215,15 @@ int run_unet(pnp_engine* e, const float* ximg, const float2* z, const float2* u,
 #endif
         Prof p(e, s, 0, li, per_layer);
         ++run_launches;
-        if (e->wino[li] && e->wplan[li].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[li], src_mode, s));
-        else if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[li], src_mode, s));
-        else HIP_TRY(launch_conv3x3(a, e->cplan[li], src_mode, s));
+        hipStream_t ls = s;
+#ifdef PNP_DIAG
+        // PNP_DIAG_STREAMS=K (timing only, results wrong): conv launch i goes to side stream i % K, so consecutive layers do NOT wait for
+        // each other - the ceiling of any scheme that overlaps a layer's tail with its successor's head (profiles/r05_ablation.md)
+        if (diag_k > 1) ls = diag_pool[li % diag_k];
+#endif
+        if (e->wino[li] && e->wplan[li].algo == 4) HIP_TRY(launch_conv3x3_winograd4(a, e->wplan[li], src_mode, ls));
+        else if (e->wino[li]) HIP_TRY(launch_conv3x3_winograd(a, e->wplan[li], src_mode, ls));
+        else HIP_TRY(launch_conv3x3(a, e->cplan[li], src_mode, ls));
         return PNP_OK;
     };
     int rc;

@@ -59,8 +59,26 @@ class Bf16Plan:
     layer_terms:   {layer index: terms} overrides (tools/bf16_drift.py)
     `True` where a plan is expected means Bf16Plan()."""
 
-    def __init__(self, acts: bool = True, weight_terms: int = 2, layer_terms=None):
+    def __init__(self, acts: bool = True, weight_terms: int = 2, layer_terms=None, lo_format: str = "bf16"):
         self.acts, self.weight_terms, self.layer_terms = acts, weight_terms, dict(layer_terms or {})
+        # lo_format (round-5 gate experiment, tools/bf16_drift.py `lo-e4m3`): "e4m3" evaluates the SECOND weight term on 8-bit operands -
+        # lo * 2^s rounded to OCP float8 e4m3 (s per layer: the largest |lo| lands just under 448) times the bf16-rounded activations
+        # rounded once more to e4m3, products exact, f32 accumulate - as the block-scaled fp8 matrix instruction would
+        self.lo_format = lo_format
+
+    def conv(self, li: int, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """conv3x3 + bias of layer li under this plan"""
+        terms = self.layer_terms.get(li, self.weight_terms)
+        if self.lo_format == "bf16" or terms != 2:
+            x, w = self.operands(li, x, w)
+            return F.conv2d(x, w, b, stride=1, padding=1)
+        xb = _bf16(x) if self.acts else x
+        hi = _bf16(w)
+        lo = w - hi
+        s = torch.floor(torch.log2(448.0 / lo.abs().max().clamp_min(1e-30)))
+        lo8 = (lo * 2.0 ** s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(w.dtype) * 2.0 ** (-s)
+        x8 = xb.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+        return F.conv2d(xb, hi, b, stride=1, padding=1) + F.conv2d(x8, lo8, None, stride=1, padding=1)
 
     def operands(self, li: int, x: torch.Tensor, w: torch.Tensor):
         if self.acts:
@@ -89,8 +107,9 @@ def _stage(sd, prefix: str, x: torch.Tensor, bf16_operands=False) -> torch.Tenso
         w = sd[f"{prefix}.conv-{j}.conv2d.weight"]
         b = sd[f"{prefix}.conv-{j}.conv2d.bias"]
         if plan is not None and w.shape[1] >= 32:
-            x, w = plan.operands(_STAGE_BASE[prefix] + j, x, w)
-        x = F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), LEAKY)
+            x = F.leaky_relu(plan.conv(_STAGE_BASE[prefix] + j, x, w, b), LEAKY)
+        else:
+            x = F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), LEAKY)
     return x
 
 

@@ -94,7 +94,7 @@ def test_denoiser_torch_default_weights(golden_dir):
     np.testing.assert_allclose(got, np.clip(g["out_tdef_128"], 0, 1), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 128, 128), (3, 64, 64), (2, 256, 256)])
+@pytest.mark.parametrize("n,h,w", [(1, 128, 128), (3, 64, 64), (2, 256, 256), (2, 512, 512), (1, 512, 256), (1, 256, 512)])
 def test_prox_dual_matches_oracle(n, h, w):
     data = synthetic.make_problem(n, h, w, accel=4.0, seed=99)
     st = O.reset(data)

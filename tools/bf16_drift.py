@@ -36,6 +36,8 @@ def plan_for(name: str):
         return O.Bf16Plan(weight_terms=0)
     if name == "w":
         return O.Bf16Plan(acts=False, weight_terms=1)
+    if name == "lo-e4m3":                   # round 5 gate: the second weight term on fp8 e4m3 operands (weights pre-scaled per layer)
+        return O.Bf16Plan(lo_format="e4m3")
     if name.startswith("w2-"):
         arg = name[3:]
         if arg == "all":                    # the engine's default since round 4
