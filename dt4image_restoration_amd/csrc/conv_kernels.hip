@@ -815,6 +815,7 @@ Tuning tuning_from_env() {
     t.bf16_no_ws = getenv("PNP_BF16_NO_WS") != nullptr;
     t.bf16_w1 = getenv("PNP_BF16_W1") != nullptr;
     t.bf16_no_holdhi = getenv("PNP_BF16_NO_HOLDHI") != nullptr;
+    t.fft_xcd = getenv("PNP_FFT_XCD") != nullptr && atoi(getenv("PNP_FFT_XCD")) != 0;
     if (const char* v = getenv("PNP_SPLITK_INLAUNCH")) t.splitk_inlaunch = atoi(v);
     if (const char* v = getenv("PNP_SLICE128_MIN_N")) t.slice128_min_n = atoi(v);
     return t;

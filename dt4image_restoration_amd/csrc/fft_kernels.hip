@@ -22,8 +22,22 @@
 
 namespace pnp {
 
+// (explicit fused form: `a.x * b.x - a.y * b.y` has two legal contractions with different roundings, and hipcc picked different ones for the
+// same pass body inlined into two kernels - the per-XCD persistent kernel and the three-launch path must agree bit for bit)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+// A complex64 load that never hits (or fills) the CU's vector L1: agent-scope relaxed atomic load = `global_load_dwordx2 ... sc1`.  The per-XCD
+// persistent kernel reads the scratch other CUs of its XCD wrote earlier in the SAME launch through this (the L2 they share is coherent, the L1s are not;
+// `buffer_inv sc0` is a no-op outside threadgroup-split mode and `buffer_inv sc1` drops the whole L2: both measured, profiles/r05_ablation.md).
+template <bool COH>
+__device__ __forceinline__ float2 ld_c64(const float2* p) {
+    if constexpr (COH) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+    } else {
+        return *p;
+    }
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -376,12 +390,12 @@ static constexpr int ROW_ELEMS = 2048;   // complex elements per workgroup in th
 // (fft256_radix16_inplace: every thread owns a butterfly, 2 LDS round trips per transform instead of 4, and the skew keeps the
 // Stockham strides off each other's banks - the radix-4 passes over unpadded 256-element lines spent 0.40 of their LDS cycles
 // in bank conflicts, profiles/r02_pmc_current.md).
-template <int MODE, int LC, bool R16 = false>
-__global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2* out,
-                                                       const float* __restrict__ x, float2* __restrict__ u,
-                                                       const float2* __restrict__ twg, const float* __restrict__ tact,
-                                                       int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+// fft_rows_body: rows [y0, y0 + rpb) of slice n, by ONE workgroup whose LDS is smem (shared by fft_rows_kernel and the per-XCD persistent kernel)
+template <int MODE, int LC, bool R16, bool COH = false>
+__device__ __forceinline__ void fft_rows_body(float2* smem, const float2* in, float2* out,
+                                              const float* __restrict__ x, float2* __restrict__ u,
+                                              const float2* __restrict__ twg,
+                                              int H, int W, int rpb, int inverse, int shift_in, int shift_out, int n, int y0) {
     static_assert(!R16 || ((LC == 256 || LC == 512) && MODE != 0), "register-resident passes: the 256- / 512-point ADMM passes");
     constexpr int RE = (R16 && LC == 256) ? 4096 : ROW_ELEMS;   // elements per workgroup (R16: 16 rows of 256 / 4 rows of 512 - every thread owns one butterfly per pass)
     constexpr int RLS = LC == 512 ? SK512_LS : SK256_LS;   // (R16) skewed line stride
@@ -389,14 +403,6 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     float2* buf0 = smem;
     float2* buf1 = smem + (R16 ? 0 : rpb * W);
     float2* tw = smem + (R16 ? (RE / (LC > 0 ? LC : 1)) * RLS : 2 * rpb * W);
-    const int blocks_per_img = H / rpb;
-    const int n = blockIdx.x / blocks_per_img;
-    const int y0 = (blockIdx.x % blocks_per_img) * rpb;
-    if (MODE != 0 && tact != nullptr && tact[n] > 0.5f) return;
-    if (MODE != 0 && shift_out > 0) {                      // (experiment, PNP_FFT_STAGGER: start phases of the workgroups that share a CU)
-        const int ph = ((int)blockIdx.x >> 8) & 3;
-        for (int i = 0; i < ph * shift_out; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     const size_t base = ((size_t)n * H + y0) * W;
     const int tot = rpb * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) tw[i] = twg[i];
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
             const int e = e0 + k * 256;
             if (e < tot) {
                 if (MODE == 1) { v[k] = u[base + e]; xv[k] = x[base + e]; }
-                else { const int r = e >> lw, c = e & (W - 1); v[k] = in[base + (size_t)r * W + (c ^ shift_in)]; }
+                else { const int r = e >> lw, c = e & (W - 1); v[k] = ld_c64<COH>(&in[base + (size_t)r * W + (c ^ shift_in)]); }
             }
         }
 #pragma unroll
@@ -468,35 +474,37 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2*
     }
 }
 
+template <int MODE, int LC, bool R16 = false>
+__global__ __launch_bounds__(256) void fft_rows_kernel(const float2* in, float2* out,
+                                                       const float* __restrict__ x, float2* __restrict__ u,
+                                                       const float2* __restrict__ twg, const float* __restrict__ tact,
+                                                       int H, int W, int rpb, int inverse, int shift_in, int shift_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int blocks_per_img = H / rpb;
+    // ADMM passes: the same (slice -> XCD) map as fft_cols_kernel - workgroups b, b + 8, ... share an XCD, each XCD takes a contiguous range of
+    // slices - so that the scratch a slice's row pass wrote is in the L2 of the XCD whose column pass reads it, and again for the inverse rows
+    int vb = blockIdx.x;
+    if (MODE != 0 && (gridDim.x & 7) == 0) vb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int n = vb / blocks_per_img;
+    const int y0 = (vb % blocks_per_img) * rpb;
+    if (MODE != 0 && tact != nullptr && tact[n] > 0.5f) return;
+    fft_rows_body<MODE, LC, R16>(smem, in, out, x, u, twg, H, W, rpb, inverse, shift_in, shift_out, n, y0);
+}
+
 // Column pass over CW adjacent columns of one slice.  MODE 0 generic in-place transform with row-index
 // shifts; MODE 1 forward -> prox -> inverse (ADMM).
-template <int MODE, int LC>
-__global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data, const float2* __restrict__ twg,
-                                                       const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
-                                                       int mask_n, const float* __restrict__ mu,
-                                                       const float* __restrict__ tact, int H, int W, int cw,
-                                                       int inverse, int shift_in, int shift_out) {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+// fft_cols_body: columns [x0, x0 + cw) of slice n, by ONE workgroup whose LDS is smem
+template <int MODE, int LC, bool COH = false>
+__device__ __forceinline__ void fft_cols_body(float2* smem, float2* __restrict__ data, const float2* __restrict__ twg,
+                                              const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
+                                              int mask_n, const float* __restrict__ mu, int H, int W, int cw,
+                                              int inverse, int shift_in, int shift_out, int n, int x0) {
     constexpr bool R16 = MODE == 1 && LC == 256;           // 256-point columns of the ADMM pass: radix-16 passes, skewed lines
     constexpr bool R8 = MODE == 1 && LC == 512;            // 512-point columns: radix-8 passes, skewed lines
     const int lstr = R16 ? SK256_LS : (R8 ? SK512_LS : H + 1);
     float2* buf0 = smem;
     float2* buf1 = smem + cw * lstr;
     float2* tw = smem + ((MODE == 1 && LC > 0) ? 1 : 2) * cw * lstr;   // the unrolled ADMM variant works in place in buf0
-    const int strips = W / cw;
-    // Workgroups b, b + 8, b + 16, ... share an XCD (and its L2) and are dispatched back to back: each XCD walks a CONTIGUOUS range of
-    // (slice, strip) pairs, so the two 8-column strips that share every 128-byte line of a 512-point slice (and of its y0 / mask) run
-    // side by side on ONE L2 - the line comes from HBM once and its two half-line stores merge before they leave (round 5: the strips of a
-    // line pair used to sit on different XCDs, 2.6 x the algorithmic bytes moved at 512 x 512, profiles/r04_pmc_current_16x512x512_f32.md)
-    int vb = blockIdx.x;
-    if ((gridDim.x & 7) == 0) vb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    const int n = vb / strips;
-    const int x0 = (vb % strips) * cw;
-    if (MODE == 1 && tact != nullptr && tact[n] > 0.5f) return;
-    if (MODE == 1 && shift_out > 0) {
-        const int ph = ((int)blockIdx.x >> 8) & 3;
-        for (int i = 0; i < ph * shift_out; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     float2* img = data + (size_t)n * H * W;
     const int tot = cw * H;
     for (int i = threadIdx.x; i < H; i += blockDim.x) tw[i] = twg[i];
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int e = e0 + k * 256;
-            if (e < tot) v[k] = img[(size_t)(e >> lcw) * W + x0 + (e & (cw - 1))];
+            if (e < tot) v[k] = ld_c64<COH>(&img[(size_t)(e >> lcw) * W + x0 + (e & (cw - 1))]);
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -613,6 +621,114 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data
             v.x *= sc; v.y *= sc;
             img[(size_t)r * W + x0 + c] = v;
         }
+    }
+}
+
+template <int MODE, int LC>
+__global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ data, const float2* __restrict__ twg,
+                                                       const float2* __restrict__ y0s, const uint8_t* __restrict__ masks,
+                                                       int mask_n, const float* __restrict__ mu,
+                                                       const float* __restrict__ tact, int H, int W, int cw,
+                                                       int inverse, int shift_in, int shift_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int strips = W / cw;
+    // Workgroups b, b + 8, b + 16, ... share an XCD (and its L2) and are dispatched back to back: each XCD walks a CONTIGUOUS range of
+    // (slice, strip) pairs, so the two 8-column strips that share every 128-byte line of a 512-point slice (and of its y0 / mask) run
+    // side by side on ONE L2 - the line comes from HBM once and its two half-line stores merge before they leave (round 5: the strips of a
+    // line pair used to sit on different XCDs, 2.6 x the algorithmic bytes moved at 512 x 512, profiles/r04_pmc_current_16x512x512_f32.md)
+    int vb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) vb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int n = vb / strips;
+    const int x0 = (vb % strips) * cw;
+    if (MODE == 1 && tact != nullptr && tact[n] > 0.5f) return;
+    fft_cols_body<MODE, LC>(smem, data, twg, y0s, masks, mask_n, mu, H, W, cw, inverse, shift_in, shift_out, n, x0);
+}
+
+// ---- 256 x 256 / 512 x 512: the whole data-fidelity stage in ONE persistent launch whose scratch never leaves an XCD's L2 (round 5) ----
+// The three launches above move 81 B/px: `work` (complex64, 8 B/px) is written and read back twice through HBM - the activation planes of the
+// convs between two stages flush every L2 - and x, u are read twice; algorithmic: 37 B/px.  Here a slice's three passes run on ONE XCD, whose
+// 4 MiB L2 holds the slice's scratch (0.5 / 2 MiB) from the pass that writes it to the pass that reads it:
+//   * workgroups are persistent (grid = what the chip holds at once) and belong to the XCD they run on: hardware register XCC_ID (= blockIdx % 8
+//     in every launch measured, exp/xcc_probe.hip; the code trusts the register, not the convention);
+//   * slice n belongs to XCD n % 8; an XCD's workgroups draw tickets from its own counter; ticket order = diagonals over (slice, pass) -
+//     pass 2 of slice d - 2, pass 1 of slice d - 1, pass 0 of slice d - so that a pass's tasks are drawn well after its predecessor's;
+//   * a task of pass p > 0 first waits until ALL tasks of pass p - 1 of its slice have signalled (one counter per slice and pass, spun on by one
+//     lane).  Waiting only ever depends on EARLIER tickets, which running workgroups hold: no co-residency assumption, no deadlock;
+//   * hand-over inside an XCD needs no fence: the writer's stores are in the XCD's L2 once `s_waitcnt vmcnt(0)` returns (the vector L1 is
+//     write-through), then it signals; the reader loads the scratch past its CU's L1 (ld_c64<true>: a CU may hold lines of `work` it read in an
+//     earlier pass of this launch) from the one L2 every CU of the XCD shares.  Counters are touched by one XCD only: their atomics meet in that L2.
+// The pass bodies are the three-launch path's own (fft_rows_body / fft_cols_body): results are bit-identical to it.
+__global__ void xcc_id_kernel(unsigned* out) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = v & 15u;
+}
+struct XcdArgs {
+    const float* x; float2* z; float2* u; float2* work;
+    const float2* tw; const float2* y0s; const uint8_t* masks; int mask_n;
+    const float* mu; const float* tact; unsigned* ctr; int N, H; unsigned epoch;
+};
+static constexpr int XCD_GRID = 1024;                      // persistent workgroups: four per CU (what fits at 37-40 KB of LDS), 128 per XCD
+static constexpr int XCD_MAX_LOCAL = 64;                   // slices per XCD the counter block holds (N <= 512)
+static constexpr int XCD_CTR_STRIDE = 1 + 3 * XCD_MAX_LOCAL + 3;   // per XCD: ticket counter, done[local slice][pass]; padded to 196 words
+
+template <int LC>
+__global__ __launch_bounds__(256) void admm_xcd_kernel(const XcdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    __shared__ int s_ticket;
+    const int H = a.H, W = a.H;                            // (run-time values, as in the three-launch kernels: rsqrtf(W) must be the same instruction)
+    constexpr int RPB = LC == 256 ? 16 : 4, CW = LC == 256 ? 16 : 8;
+    constexpr int T0 = LC / RPB, T1 = LC / CW;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    unsigned* const q = a.ctr + xcd * XCD_CTR_STRIDE;
+    const int S = a.N > xcd ? (a.N - xcd + 7) / 8 : 0;       // this XCD's slices: xcd, xcd + 8, ...
+    const int total = S * (T0 + T1 + T0);
+    // The counters are never reset: launch k of a handle starts from what k - 1 left (epoch = k).  Every workgroup draws tickets until one is
+    // past the end, so a launch advances an XCD's ticket counter by total + gridDim.x / 8 (the XCD's workgroups: XCC_ID == blockIdx % 8,
+    // checked at pnp_create) and each completion counter by its pass's task count; differences are taken in unsigned arithmetic.
+    const unsigned tbase = a.epoch * (unsigned)(total + (int)(gridDim.x >> 3));
+    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(&q[0], 1u) - tbase);
+    for (;;) {
+        __syncthreads();                                   // s_ticket is written; the previous task's LDS reads are done
+        int t = __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();
+        if (t >= total) break;
+        if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(&q[0], 1u) - tbase);   // the NEXT ticket: its round trip runs under this task
+        // ticket -> (local slice ls, pass p, item): diagonal d holds pass 0 of slice d, pass 1 of d - 1, pass 2 of d - 2, in that order - a
+        // pass's tasks are drawn a whole pass of the next slice after its predecessor's
+        int ls = 0, ps = 0, item = 0;
+        for (int d = 0; d < S + 2; ++d) {
+            bool hit = false;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int sl = d - p, cnt = p == 1 ? T1 : T0;
+                if (!hit && sl >= 0 && sl < S) {
+                    if (t < cnt) { ls = sl; ps = p; item = t; hit = true; }
+                    else t -= cnt;
+                }
+            }
+            if (hit) break;
+        }
+        const int n = xcd + 8 * ls;
+        if (ps > 0) {
+            if (threadIdx.x == 0) {
+                const unsigned need = ps == 1 ? T0 : T1;
+                const unsigned dbase = a.epoch * need;
+                while (__hip_atomic_load(&q[1 + 3 * ls + ps - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - dbase < need) __builtin_amdgcn_s_sleep(24);       // (~1500 cycles between polls: dozens of waiting workgroups poll ONE L2 line, and the signal they wait for is an atomic on it)
+            }
+            __syncthreads();
+            // (no cache maintenance: the passes read the scratch with L1-bypassing loads, ld_c64<true>)
+        }
+        if (!(a.tact != nullptr && a.tact[n] > 0.5f)) {
+            if (ps == 0) fft_rows_body<1, LC, true, true>(smem, nullptr, a.work, a.x, a.u, a.tw, H, W, RPB, 0, 0, 0, n, item * RPB);
+            else if (ps == 1) fft_cols_body<1, LC, true>(smem, a.work, a.tw, a.y0s, a.masks, a.mask_n, a.mu, H, W, CW, 0, 0, 0, n, item * CW);
+            else fft_rows_body<2, LC, true, true>(smem, a.work, a.z, a.x, a.u, a.tw, H, W, RPB, 1, 0, 0, n, item * RPB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's stores are in the XCD's L2
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&q[1 + 3 * ls + ps], 1u);
     }
 }
 
@@ -843,10 +959,6 @@ hipError_t launch_fft_cols_generic(float2* data, const float2* tw, int batch, in
     return hipGetLastError();
 }
 // 256-point rows: the radix-16 variant (16 rows per workgroup); PNP_FFT_ROWS_R4 (experiments) keeps the radix-4 passes
-static int fft_stagger() {
-    static const int v = getenv("PNP_FFT_STAGGER") ? atoi(getenv("PNP_FFT_STAGGER")) : 0;
-    return v;
-}
 static bool rows_r16(int H, int W) {
     static const bool off = getenv("PNP_FFT_ROWS_R4") != nullptr;
     return !off && ((W == 256 && H % 16 == 0) || (W == 512 && H % 4 == 0));
@@ -858,10 +970,10 @@ hipError_t launch_fft_rows_fwd_admm(const float* x, const float2* u, float2* wor
     if (rows_r16(H, W)) {
         if (W == 512)
             hipLaunchKernelGGL((fft_rows_kernel<1, 512, true>), dim3(N * (H / 4)), dim3(256), (size_t)(4 * SK512_LS + W) * sizeof(float2), s,
-                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 4, 0, 0, fft_stagger());
+                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 4, 0, 0, 0);
         else
             hipLaunchKernelGGL((fft_rows_kernel<1, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
-                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 16, 0, 0, fft_stagger());
+                               nullptr, work, x, const_cast<float2*>(u), tw, tact, H, W, 16, 0, 0, 0);
         return hipGetLastError();
     }
     const int rpb = rows_per_block(H, W);
@@ -884,7 +996,7 @@ hipError_t launch_fft_cols_prox(float2* work, const float2* tw, const float2* y0
     if (hipError_t e = raise_lds_cap()) return e;
 #define PNP_COLS_PROX(LC_)                                                                                    \
     hipLaunchKernelGGL((fft_cols_kernel<1, LC_>), dim3(N * (W / cw)), dim3(256), lds, s, work, tw, y0s, masks, mask_n, mu, \
-                       tact, H, W, cw, 0, 0, fft_stagger())
+                       tact, H, W, cw, 0, 0, 0)
     const bool ct = cw == (H <= 256 ? 16 : (H <= 512 ? 8 : 4)) && (H == 128 || H == 256 || H == 512);   // W >= one full strip
     if (ct) lds = (size_t)(cw * (H == 256 ? SK256_LS : (H == 512 ? SK512_LS : H + 1)) + H) * sizeof(float2);      // in place: one strip buffer
     if (ct && H == 128) PNP_COLS_PROX(128);
@@ -899,10 +1011,10 @@ hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* 
     if (rows_r16(H, W)) {
         if (W == 512)
             hipLaunchKernelGGL((fft_rows_kernel<2, 512, true>), dim3(N * (H / 4)), dim3(256), (size_t)(4 * SK512_LS + W) * sizeof(float2), s,
-                               work, z, x, u, tw, tact, H, W, 4, 1, 0, fft_stagger());
+                               work, z, x, u, tw, tact, H, W, 4, 1, 0, 0);
         else
             hipLaunchKernelGGL((fft_rows_kernel<2, 256, true>), dim3(N * (H / 16)), dim3(256), (size_t)(16 * SK256_LS + W) * sizeof(float2), s,
-                               work, z, x, u, tw, tact, H, W, 16, 1, 0, fft_stagger());
+                               work, z, x, u, tw, tact, H, W, 16, 1, 0, 0);
         return hipGetLastError();
     }
     const int rpb = rows_per_block(H, W);
@@ -916,6 +1028,54 @@ hipError_t launch_fft_rows_inv_admm(const float2* work, const float* x, float2* 
     else if (ct && W == 512) PNP_ROWS_INV(512);
     else PNP_ROWS_INV(0);
 #undef PNP_ROWS_INV
+    return hipGetLastError();
+}
+
+// ---- the per-XCD persistent form of the stage (admm_xcd_kernel) --------------------------------------------------------------
+size_t admm_xcd_counter_bytes() { return sizeof(unsigned) * 8 * XCD_CTR_STRIDE; }
+// Square 256 / 512 slices (tw_w == tw_h), at least one slice per XCD, at most XCD_MAX_LOCAL per XCD, and a device whose launches spread
+// over eight XCDs (checked once per device with a probe launch: eight distinct XCC ids, equally often).
+bool admm_xcd_usable(int N, int H, int W) {
+    if (!(H == W && (H == 256 || H == 512)) || N < 8 || N > 8 * XCD_MAX_LOCAL) return false;
+    static int verdict[64] = {0};                          // per device ordinal: 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (verdict[dev] == 0) {
+        verdict[dev] = 2;
+        hipDeviceProp_t pr;
+        unsigned* d = nullptr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256 && hipMalloc((void**)&d, sizeof(unsigned) * 8 * XCD_CTR_STRIDE) == hipSuccess) {
+            std::vector<unsigned> h(1024);
+            unsigned* ids = nullptr;
+            if (hipMalloc((void**)&ids, sizeof(unsigned) * 1024) == hipSuccess) {
+                hipLaunchKernelGGL(xcc_id_kernel, dim3(1024), dim3(64), 0, 0, ids);
+                if (hipMemcpy(h.data(), ids, sizeof(unsigned) * 1024, hipMemcpyDeviceToHost) == hipSuccess) {
+                    int cnt[8] = {0}; bool ok = true;
+                    for (unsigned v : h) { if (v > 7u) ok = false; else ++cnt[v]; }
+                    for (int i = 0; i < 8; ++i) ok = ok && cnt[i] == 128;
+                    if (ok) verdict[dev] = 1;
+                }
+                (void)hipFree(ids);
+            }
+            (void)hipFree(d);
+        }
+    }
+    return verdict[dev] == 1;
+}
+hipError_t launch_admm_xcd(const float* x, float2* z, float2* u, float2* work, const float2* tw, const float2* y0s,
+                           const uint8_t* masks, int mask_n, const float* mu, const float* tact, unsigned* ctr, unsigned epoch, int N, int H, hipStream_t s) {
+    XcdArgs a{x, z, u, work, tw, y0s, masks, mask_n, mu, tact, ctr, N, H, epoch};
+    if (H == 256) {
+        constexpr int LDS = (16 * SK256_LS + 256) * (int)sizeof(float2);
+        static DeviceOnce once;
+        if (hipError_t e = pnp::raise_lds_cap((const void*)admm_xcd_kernel<256>, LDS, once); e != hipSuccess) return e;
+        hipLaunchKernelGGL(admm_xcd_kernel<256>, dim3(XCD_GRID), dim3(256), LDS, s, a);
+    } else {
+        constexpr int LDS = (8 * SK512_LS + 512) * (int)sizeof(float2);
+        static DeviceOnce once;
+        if (hipError_t e = pnp::raise_lds_cap((const void*)admm_xcd_kernel<512>, LDS, once); e != hipSuccess) return e;
+        hipLaunchKernelGGL(admm_xcd_kernel<512>, dim3(XCD_GRID), dim3(256), LDS, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -98,6 +98,8 @@ struct pnp_engine {
     // data-fidelity stage
     FftPlan plan = {};
     float2* d_work = nullptr;   // [N,H,W] complex scratch
+    unsigned* d_fftq = nullptr; // per-XCD ticket / completion counters of the persistent data-fidelity kernel (nullptr: three launches)
+    unsigned fftq_epoch = 0;    // launches of that kernel since the counters were zeroed (they are never reset: the kernel subtracts epoch x per-launch advance)
     float2* d_y0s = nullptr;    // [N,H,W] sgn * S y0
     uint8_t* d_masks = nullptr; // [mask_n,H,W] S mask
     int mask_n = 1;
@@ -286,6 +288,12 @@ int run_prox_dual(pnp_engine* e, const float* mu, const float* tact, const float
         HIP_TRY(launch_admm_slice128(x, z, u, e->plan.tw_w, e->d_y0s, e->d_masks, e->mask_n, mu, tact, N, s));
         return PNP_OK;
     }
+    if (e->d_fftq != nullptr) {                           // square 256 / 512 slices, >= 8 of them: one persistent launch, scratch stays in L2
+        Prof p(e, s, 4, -1);
+        HIP_TRY(launch_admm_xcd(x, z, u, e->d_work, e->plan.tw_w, e->d_y0s, e->d_masks, e->mask_n, mu, tact, e->d_fftq, e->fftq_epoch, N, H, s));
+        ++e->fftq_epoch;
+        return PNP_OK;
+    }
     {
         Prof p(e, s, 3, -1);
         HIP_TRY(launch_fft_rows_fwd_admm(x, u, e->d_work, e->plan.tw_w, tact, N, H, W, s));
@@ -431,6 +439,11 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
         hipMalloc((void**)&e->d_masks, N * H * W) != hipSuccess)
         return fail(PNP_ERR_NOMEM, "k-space scratch");
     e->ws_bytes += 2 * cbytes + N * H * W;
+    if (e->tune.fft_xcd && admm_xcd_usable(cfg->n, cfg->h, cfg->w)) {
+        if (hipMalloc((void**)&e->d_fftq, admm_xcd_counter_bytes()) != hipSuccess || hipMemset(e->d_fftq, 0, admm_xcd_counter_bytes()) != hipSuccess)
+            return fail(PNP_ERR_NOMEM, "data-fidelity work queues");
+        e->ws_bytes += admm_xcd_counter_bytes();
+    }
     e->plan.h = cfg->h; e->plan.w = cfg->w;
     int rc;
     if ((rc = make_twiddles(cfg->h, &e->plan.tw_h)) || (rc = make_twiddles(cfg->w, &e->plan.tw_w))) return rc;
@@ -477,7 +490,7 @@ int pnp_destroy(pnp_handle e) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < N_LAYERS; ++i) { (void)hipFree(e->d_wpack[i]); (void)hipFree(e->d_bias[i]); }
     for (auto& L : e->lv) { (void)hipFree(L.p); (void)hipFree(L.q); (void)hipFree(L.s); (void)hipFree(L.pool); }
-    (void)hipFree(e->d_work); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial); (void)hipFree(e->d_arrive);
+    (void)hipFree(e->d_work); (void)hipFree(e->d_fftq); (void)hipFree(e->d_y0s); (void)hipFree(e->d_masks); (void)hipFree(e->d_partial); (void)hipFree(e->d_arrive);
     (void)hipFree(e->plan.tw_h); (void)hipFree(e->plan.tw_w);
     for (auto& p : e->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete e;

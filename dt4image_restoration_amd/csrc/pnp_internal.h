@@ -31,6 +31,8 @@ struct Tuning {
     int f4_order = 1;             // PNP_WINO_F4_ORDER (experiments): 0 = spatial tiles dealt round-robin over the XCDs (rounds 1-2)
     int splitk_inlaunch = 0;      // PNP_SPLITK_INLAUNCH (experiments): 1 = split-K planes combined inside the conv launch (agent-scope accesses,
                                   // no fence) instead of by splitk_reduce_kernel
+    bool fft_xcd = false;         // PNP_FFT_XCD=1 (experiment, off by default: it moves half the bytes and is slower, profiles/r05_ablation.md): the
+                                  // data-fidelity stage of square 256 / 512 slices as ONE persistent launch with per-XCD work queues
     int slice128_min_n = 192;     // PNP_SLICE128_MIN_N: 128 x 128 slices take the one-workgroup-per-slice data-fidelity kernel from
                                   // this batch size on (measured: one workgroup per slice is LDS-bound on its CU - 46 us a slice - so it
                                   // needs a chip-filling batch to beat the three-launch path: 64.1 vs 78.8 us at 256 slices, 48.9 vs 34.9 at 64)
@@ -174,6 +176,11 @@ hipError_t launch_admm_slice128(const float* x, float2* z, float2* u, const floa
 hipError_t launch_reset(const float2* x0, const float2* y0, const uint8_t* mask, int mask_n, float* x, float2* z,
                         float2* u, float2* y0s, uint8_t* masks, int N, int H, int W, hipStream_t s);
 hipError_t launch_finish(const float* tact, float* tstate, uint8_t* done, int N, hipStream_t s);
+// the whole stage as ONE persistent launch with per-XCD work queues (fft_kernels.hip, admm_xcd_kernel); ctr: admm_xcd_counter_bytes() of device memory
+size_t admm_xcd_counter_bytes();
+bool admm_xcd_usable(int N, int H, int W);
+hipError_t launch_admm_xcd(const float* x, float2* z, float2* u, float2* work, const float2* tw, const float2* y0s,
+                           const uint8_t* masks, int mask_n, const float* mu, const float* tact, unsigned* ctr, unsigned epoch, int N, int H, hipStream_t s);
 hipError_t launch_psnr(const float* x, const float* gt, float* out, int N, int HW, hipStream_t s);
 
 }  // namespace pnp

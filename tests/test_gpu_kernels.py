@@ -120,6 +120,58 @@ def test_prox_dual_matches_oracle(n, h, w):
     np.testing.assert_allclose(torch.view_as_real(ug.cpu()).numpy(), torch.view_as_real(un).numpy(), rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("n,h,per_slice_masks", [(8, 256, False), (19, 256, True), (16, 512, False), (9, 512, True)])
+def test_prox_dual_per_xcd_persistent_kernel_is_bit_identical_to_three_launches(n, h, per_slice_masks, monkeypatch):
+    """Round 5 (PNP_FFT_XCD=1, an experiment that stays off by default: it halves the stage's HBM bytes and is slower): square 256 / 512 slices,
+    >= 8 of them, run the data-fidelity stage (env.py:87-93) as ONE persistent launch whose workgroups draw (slice, pass) tasks from per-XCD queues
+    so that the complex scratch stays in that XCD's L2 (admm_xcd_kernel).  Same pass bodies as the three-launch path: bit-identical z and u, call
+    after call (the counters are never reset), with a third of the slices stopped (they must stay untouched), ragged slice counts per XCD, one mask
+    per slice - and against the oracle."""
+    from dt4image_restoration_amd.engine import PnPEngine
+    w = h
+    datas = [synthetic.make_problem(1, h, w, accel=(2.0, 4.0, 8.0)[i % 3], seed=70 + i) for i in range(n if per_slice_masks else 1)]
+    if per_slice_masks:
+        masks = torch.stack([torch.from_numpy(np.asarray(d["mask"])).reshape(h, w).bool() for d in datas])
+        y0 = torch.cat([torch.view_as_complex(torch.from_numpy(d["y0"])) for d in datas])
+        x0 = torch.cat([torch.view_as_complex(torch.from_numpy(d["x0"])) for d in datas])
+    else:
+        d = synthetic.make_problem(n, h, w, accel=4.0, seed=71)
+        masks = torch.from_numpy(np.asarray(d["mask"])).reshape(h, w).bool()
+        y0 = torch.view_as_complex(torch.from_numpy(d["y0"])); x0 = torch.view_as_complex(torch.from_numpy(d["x0"]))
+    xd = torch.clamp(x0.real + 0.05 * torch.from_numpy(synthetic.hash_uniform(11, 1, n * h * w).reshape(n, 1, h, w)), 0, 1)
+    u0 = 0.1 * torch.view_as_complex(torch.from_numpy(synthetic.hash_uniform(11, 2, 2 * n * h * w).reshape(n, 1, h, w, 2).copy()))
+    mu = torch.linspace(0.05, 0.6, n)
+    tact = torch.zeros(n); tact[1::3] = 0.9                 # every third slice has stopped (T > 0.5, env.py:79-81)
+    outs = {}
+    for name in ("three", "xcd"):
+        if name == "xcd":
+            monkeypatch.setenv("PNP_FFT_XCD", "1")
+        e = PnPEngine(n, h, w)
+        monkeypatch.delenv("PNP_FFT_XCD", raising=False)
+        e.reset(x0.cuda(), y0.cuda(), masks.cuda())
+        res = []
+        for rep in range(4):                                # the scratch and the counters are reused call after call
+            xg, ug = xd.cuda(), u0.cuda().clone()
+            zg = torch.full_like(ug, 7.0)
+            e.prox_dual(xg, zg, ug, mu.cuda(), tact.cuda())
+            res.append((torch.view_as_real(zg).clone(), torch.view_as_real(ug).clone()))
+        for r in res[1:]:
+            assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
+        outs[name] = res[0]
+    assert torch.equal(outs["xcd"][0], outs["three"][0]) and torch.equal(outs["xcd"][1], outs["three"][1])
+    zg, ug = torch.view_as_complex(outs["xcd"][0].cpu()), torch.view_as_complex(outs["xcd"][1].cpu())
+    for i in (0, 1, n - 1):
+        if tact[i] > 0.5:                                   # stopped: z left as handed in, u unchanged
+            assert float((zg[i] - 7.0).abs().max()) == 0.0 and torch.equal(ug[i], u0[i])
+            continue
+        mk = masks[i] if per_slice_masks else masks
+        zf = O.fft2c(xd[i:i + 1] + u0[i:i + 1])
+        zn = O.ifft2c(torch.where(mk.reshape(1, 1, h, w), (mu[i] * zf + y0[i:i + 1]) / (1 + mu[i]), zf))
+        # FLOAT TOLERANCE: two f32 FFTs + pointwise, data O(1)
+        np.testing.assert_allclose(torch.view_as_real(zg[i:i + 1]).numpy(), torch.view_as_real(zn).numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(torch.view_as_real(ug[i:i + 1]).numpy(), torch.view_as_real(u0[i:i + 1] + xd[i:i + 1] - zn).numpy(), rtol=0, atol=5e-6)
+
+
 @pytest.mark.parametrize("h,w", [(64, 64), (128, 256), (256, 64)])
 def test_prox_dual_per_slice_masks_and_non_square(h, w):
     """mask_n == N (the reference's z[mask] needs a mask of z's shape for N > 1): every slice its own sampling
