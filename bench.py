@@ -40,7 +40,7 @@ def mfma_conv_flops(n, h, w):
                    for l in unet_spec.UNET_LAYERS[1:27])
 
 
-TRAFFIC_ROUNDS = ("r04", "r03", "r02", "r01")     # newest first
+TRAFFIC_ROUNDS = ("r05", "r04", "r03", "r02", "r01")     # newest first
 
 
 def pmc_traffic(n, h, w, which, mode="f32"):

@@ -287,7 +287,7 @@ __device__ __forceinline__ void fft256_radix16_inplace(float2* buf, const float2
 // reads positions b + 64 m and writes 8 b + q (Ns = 1), 64 (b >> 3) + (b & 7) + 8 q (Ns = 8), b + 64 q (Ns = 64); under the skew these
 // are sk(b) + 72 m, 9 b + q, 72 (b >> 3) + (b & 7) + 9 q, sk(b) + 72 q: consecutive lanes b stay on distinct banks in all of them.
 // Lines SK512_LS elements apart.
-static constexpr int SK512_LS = 576;   // (8 lines + the twiddle table = 40 KiB: four workgroups per CU)
+static constexpr int SK512_LS = 577;   // odd: the column kernel stages and solves ACROSS lines (8 lanes = 8 lines at one row): a stride that is a multiple of the bank count puts them all on one bank (measured: bank-conflict share 0.65 with 576)
 __device__ __forceinline__ int sk512(int i) { return i + (i >> 3); }
 
 // v[0..7] -> its 8-point DFT, result X[q] in v[4 (q & 1) + (q >> 1)] (one radix-2 stage, constant twiddles w8^k, two radix-4 stages)
