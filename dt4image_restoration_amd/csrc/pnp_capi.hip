@@ -573,6 +573,11 @@ int pnp_reset(pnp_handle e, const float* x0, const float* y0, const uint8_t* mas
         return fail(PNP_ERR_INVALID, "pnp_reset: the k-space stage needs power-of-two h, w (got %dx%d)", e->cfg.h, e->cfg.w);
     PNP_ON_DEVICE(e);
     e->mask_n = mask_n;
+    // the two experimental in-launch hand-over schemes keep counters between launches (PNP_SPLITK_INLAUNCH: arrival counters that return to zero;
+    // PNP_FFT_XCD: ticket / completion counters read against a launch epoch): a launch that faulted half way would leave them out of step for good,
+    // so an episode starts from zero
+    if (e->d_arrive) HIP_TRY(hipMemsetAsync(e->d_arrive, 0, 4096 * sizeof(unsigned), (hipStream_t)stream));
+    if (e->d_fftq) { HIP_TRY(hipMemsetAsync(e->d_fftq, 0, admm_xcd_counter_bytes(), (hipStream_t)stream)); e->fftq_epoch = 0; }
     HIP_TRY(launch_reset((const float2*)x0, (const float2*)y0, mask, mask_n, x, (float2*)z, (float2*)u, e->d_y0s,
                          e->d_masks, e->cfg.n, e->cfg.h, e->cfg.w, (hipStream_t)stream));
     e->reset_done = true;
