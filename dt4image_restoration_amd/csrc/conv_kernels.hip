@@ -293,7 +293,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
     };
     // UPCAT geometry of this tile: low-res rows/cols [ylo, ylo+LH) x [xlo, xlo+LW) cover every source pixel of the patch
     const int Hs = a.H >> 1, Ws = a.W >> 1;
-    const int ylo = UP2 ? (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0)) : 0;
+    // SEP (bf16 operands, round 5): the upsampled chunks interpolate separably, as the producers of conv3x3_bf16ws_kernel do - a task's four
+    // horizontal lerps once, one vertical lerp of two COMPILE-TIME lines per patch row (upsample_lines_regular(), checked by pnp_create);
+    // the region then starts at line ty0 / 2 - 1 (a zero line above the image)
+    constexpr bool SEP = UP2 && BF16 != 0;
+    const int ylo = UP2 ? (SEP ? ty0 / 2 - 1 : (int)(a.rh * (float)(ty0 > 0 ? ty0 - 1 : 0))) : 0;
     const int xlo = UP2 ? (int)(a.rw * (float)(tx0 > 0 ? tx0 - 1 : 0)) : 0;
     const int nskip = UP2 ? a.Cskip / CK : 0;             // leading chunks that come straight from the skip tensor
 
@@ -353,8 +357,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             const int idx = tid + k * 256;
             const int part = idx % PPP, pp = idx / PPP;
             const int sy = ylo + pp / LW, sx = xlo + pp % LW;
-            if (idx < LITEMS && sy < Hs && sx < Ws)
+            if (idx < LITEMS && sy >= 0 && sy < Hs && sx < Ws)
                 rawu[k] = *reinterpret_cast<const float4*>(base + ((size_t)sy * Ws + sx) * Cup + part * 4);
+            else if constexpr (SEP) rawu[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // (lines the separable form multiplies by a zero weight must be finite)
         }
     };
     auto commit_lo = [&]() {
@@ -366,6 +371,40 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
             if (idx < LITEMS) *reinterpret_cast<float4*>(&lowres[(idx / PPP) * CKL + (idx % PPP) * 4]) = rawu[k];
         }
         __syncthreads();
+        if constexpr (SEP) {
+            // task = (group of 6 patch rows, patch column, 4-channel part): ~7 vector instructions per stored piece instead of 27.  All
+            // arithmetic through lerp_np (conv_staging.h): this kernel's other waves run bf16 MFMAs (profiles/r05_race.md).
+            constexpr int NG = (PH + 5) / 6, TPG = PWL * PPP, TASKS = NG * TPG, ROUNDS = (TASKS + 255) / 256;
+            static_assert(3 * (NG - 1) + 3 < LH, "a group's four source lines are inside the parked region");
+#pragma unroll 1
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int T = tid + 256 * rd;
+                if (T < TASKS) {
+                    const int rg = T / TPG, rest = T - rg * TPG, px = rest / PPP, pt = rest % PPP;
+                    const float4 ct = *reinterpret_cast<const float4*>(&colT[4 * px]);
+                    const float* l0 = &lowres[(3 * rg) * (LW * CKL) + pt * 4];
+                    const int c0 = __float_as_int(ct.x), c1 = __float_as_int(ct.y);
+                    float4 h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 u = *reinterpret_cast<const float4*>(l0 + j * (LW * CKL) + c0);
+                        const float4 v = *reinterpret_cast<const float4*>(l0 + j * (LW * CKL) + c1);
+                        h[j] = make_float4(lerp_np(ct.z, u.x, ct.w, v.x), lerp_np(ct.z, u.y, ct.w, v.y), lerp_np(ct.z, u.z, ct.w, v.z), lerp_np(ct.z, u.w, ct.w, v.w));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int py = 6 * rg + i;
+                        if (py < PH) {
+                            const float2 rw = *reinterpret_cast<const float2*>(&rowT[4 * py]);
+                            const float4 &ha = h[i >> 1], &hb = h[(i >> 1) + 1];
+                            store_patch(py, px, pt, make_float4(lerp_np(rw.x, ha.x, rw.y, hb.x), lerp_np(rw.x, ha.y, rw.y, hb.y),
+                                                                lerp_np(rw.x, ha.z, rw.y, hb.z), lerp_np(rw.x, ha.w, rw.y, hb.w)));
+                        }
+                    }
+                }
+            }
+            return;
+        }
         // the interpolation's coordinates are the same for every chunk: one table entry per patch row and column (built once,
         // below); a pixel outside the image has zero weights = the conv's zero padding
 #pragma unroll 2
@@ -398,6 +437,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_mfma_kernel(const ConvArgs a
                 const float l = fminf(fmaxf(sc - (float)i0, 0.f), 1.f);
                 const int lo = isrow ? ylo : xlo, mul = isrow ? LW * CKL : CKL;
                 e = make_float4(__int_as_float((i0 - lo) * mul), __int_as_float((i1 - lo) * mul), 1.f - l, l);
+                if (SEP && isrow) {                       // {weight of line s0, weight of line s0 + 1}, s0 = ylo + (row >> 1)
+                    const int s0 = ylo + (pq >> 1);
+                    e = make_float4((i0 == s0 ? 1.f - l : 0.f) + (i1 == s0 ? l : 0.f), (i0 == s0 + 1 ? 1.f - l : 0.f) + (i1 == s0 + 1 ? l : 0.f), 0.f, 0.f);
+                }
             }
             *reinterpret_cast<float4*>(&(isrow ? rowT : colT)[4 * pq]) = e;
         }
