@@ -252,6 +252,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16ws_kernel(const ConvArgs a) {
                     const float* o = &ew[(2 * qx) * OSTR + 4 * c4];
                     const float4 m = act4(f4max(f4max(*reinterpret_cast<const float4*>(o), *reinterpret_cast<const float4*>(o + OSTR)),        // (monotonic:
                                                 f4max(*reinterpret_cast<const float4*>(o + TW * OSTR), *reinterpret_cast<const float4*>(o + TW * OSTR + OSTR))));   // = max of the activations)
+                    if (a.act16 & 4) {                     // bf16 pooled copy (rounding is monotonic too: its reader would round these very values)
+                        uint2 o16;
+                        o16.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){m.x, m.y}, bf16x2));
+                        o16.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){m.z, m.w}, bf16x2));
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.pooled) + (((size_t)n * Hp + gy) * Wp + gx) * 32 + 4 * c4) = o16;
+                    } else
                     *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + gy) * Wp + gx) * 32 + 4 * c4) = m;
                 }
             }

@@ -432,6 +432,14 @@ static int create_impl(const pnp_config* cfg, pnp_engine* e) {
                 if ((li < 3 || li > 23) && !in16) out16[li] = false;
                 e->abits[li] = (uint8_t)((in16 ? 1 : 0) | (out16[li] ? 2 : 0));
             }
+            // round 5: level 0's pooled copy (inc.conv-2 -> down1.conv-0) as bf16 too when both layers run the producer / consumer kernel:
+            // rounding to nearest even is monotonic, so bf16(max(a, b, c, d)) == max(bf16(a), ...) - the bits down1.conv-0 stages are the
+            // ones it rounded the f32 copy to, at half the bytes written and read (bit 2 of the writer's act16, bit 0 of the reader's)
+            if ((e->abits[2] & 2) && e->cplan[2].ws && e->cplan[3].ws && e->cplan[2].holdhi && e->bf16_terms == 2 && e->pool_ok[0] &&
+                kLayers[3].src == SRC_POOL) {
+                e->abits[2] |= 4;
+                e->abits[3] |= 1;
+            }
         }
     }
     const size_t cbytes = N * H * W * sizeof(float2);

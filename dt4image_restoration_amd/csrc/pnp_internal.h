@@ -76,7 +76,8 @@ struct ConvArgs {
     float rh, rw;        // UPCAT: (H/2-1)/(H-1), (W/2-1)/(W-1)  (bilinear align_corners=True scale)
     int bf16;            // bf16 MFMA operands (wpack = pack_conv3x3_weights_bf16), f32 accumulate: 0 = off, 2 = weights as two bf16 terms
                          // hi + lo (the mode's default), 1 = one term (PNP_BF16_W1)
-    int act16;           // bf16 mode, 32-channel plan: bit 0 = src0 (PLAIN source / UPCAT skip) holds bf16, 2 B per channel; bit 1 = dst too
+    int act16;           // bf16 mode, 32-channel plan: bit 0 = src0 (PLAIN source / UPCAT skip) holds bf16, 2 B per channel; bit 1 = dst too;
+                         // bit 2 = the pooled copy is written as bf16 (producer / consumer kernel's OFFLOAD store only)
     int order;           // F(4x4): blockIdx -> tile order (wino4_decode), from the plan
 #ifdef PNP_STAMPS
     int stamp_slot;      // diagnostic build: launch index into the stamp buffer (winograd_kernels.hip)
