@@ -93,9 +93,17 @@ __global__ __launch_bounds__(512) void probe(const float4* __restrict__ wts, uns
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
                                 if constexpr (MF == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[mt]), __builtin_bit_cast(bf16x8, b0[nt][w]), acc[mt][nt], 0, 0, 0);
-                                else {                  // f32 MFMAs (they hold the vector issue port): 4 x 32x32x2 = the same 32 cycles... of a k-step
+                                else if constexpr (MF == 1) {   // f32 MFMAs (they hold the vector issue port)
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].x, b0[nt][w].x, acc[mt][nt], 0, 0, 0);
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt].y, b0[nt][w].y, acc[mt][nt], 0, 0, 0);
+                                } else {                        // the F(4x4) kernels' shape: v_mfma_f32_16x16x4_f32 (four per 32 x 32 block and k-step)
+                                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        f32x4 c = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(q & 1 ? a0[mt].y : a0[mt].x, q & 2 ? b0[nt][w].y : b0[nt][w].x, c, 0, 0, 0);
+                                        acc[mt][nt][4 * q] = c[0]; acc[mt][nt][4 * q + 1] = c[1]; acc[mt][nt][4 * q + 2] = c[2]; acc[mt][nt][4 * q + 3] = c[3];
+                                    }
                                 }
                 } else {
 #pragma unroll
@@ -203,6 +211,9 @@ int main() {
         mk<1, 1, 1>("pk_mul op_sel:[0,1] | f32 MFMA"),
         mk<5, 1, 1>("pk_mul op_sel:[0,1] | f32 MFMA + global loads"),
         mk<7, 1, 1>("pk_mul op_sel:[0,1] | f32 MFMA + LDS reads + global loads"),
+        mk<5, 1, 2>("pk_mul op_sel:[0,1] | f32 16x16x4 MFMA + global loads"),
+        mk<7, 1, 2>("pk_mul op_sel:[0,1] | f32 16x16x4 MFMA + LDS reads + global loads"),
+        mk<5, 2, 2>("pk_fma op_sel:[0,1,0] op_sel_hi:[1,0,1] | f32 16x16x4 MFMA + global loads"),
     };
     for (auto& c : cases) (void)hipFuncSetAttribute(c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     for (int rep = 0; rep < 1; ++rep)
